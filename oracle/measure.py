@@ -1,0 +1,151 @@
+"""ORACLE (test infrastructure only -- never imported by shapy_amd/).
+
+CPU restatement of the virtual-measurement path:
+  * ``mesh_to_mesh_forward``  -> oracle/mesh_intersect.c (brute force over all pairs)
+  * ``BodyMeasurements``      -> NumPy + scipy.spatial.ConvexHull, following
+    mesh-mesh-intersection/body_measurements/body_measurements.py:86-97,99-215
+
+Pinned by tests/golden/img_00_pins.npz: the reference's shipped SHAPY_A result
+(mass 56.868896, height 1.6437092, chest 0.8745367, waist 0.7651476, hips 0.9546815).
+"""
+import ctypes
+import os
+import os.path as osp
+import subprocess
+
+import numpy as np
+import yaml
+
+_HERE = osp.dirname(osp.abspath(__file__))
+_LIB = None
+DENSITY = 985.0                      # body_measurements.py:20
+
+f32 = np.float32
+
+
+def build(force=False):
+    so = osp.join(_HERE, '_build', 'liboracle.so')
+    src = osp.join(_HERE, 'mesh_intersect.c')
+    if force or not osp.exists(so) or osp.getmtime(so) < osp.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-s', '-B' if force else '-s'])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        fp = ctypes.POINTER(ctypes.c_float)
+        L.shapy_oracle_mesh_to_mesh.restype = ctypes.c_long
+        L.shapy_oracle_mesh_to_mesh.argtypes = [
+            fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+            ctypes.POINTER(ctypes.c_int64), fp]
+        L.shapy_oracle_tri_tri_sat.restype = ctypes.c_int
+        L.shapy_oracle_tri_tri_sat.argtypes = [fp, fp]
+        L.shapy_oracle_tri_tri_point.restype = ctypes.c_int
+        L.shapy_oracle_tri_tri_point.argtypes = [fp, fp, fp]
+        _LIB = L
+    return _LIB
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def mesh_to_mesh_forward(query, target, max_collisions=16):
+    """query [B,Q,3,3] f32, target [B,F,3,3] f32 -> (faces int64 [B,Q*MC], bcs f32 [B,Q*MC,2,3]).
+    mesh_mesh_intersect.cpp:36-57."""
+    query = np.ascontiguousarray(query, f32)
+    target = np.ascontiguousarray(target, f32)
+    B, Q = query.shape[:2]
+    F = target.shape[1]
+    faces = np.empty((B, Q * max_collisions), np.int64)
+    bcs = np.empty((B, Q * max_collisions, 2, 3), f32)
+    dropped = lib().shapy_oracle_mesh_to_mesh(
+        _fp(query), _fp(target), B, Q, F, max_collisions,
+        faces.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _fp(bcs))
+    mesh_to_mesh_forward.last_dropped = int(dropped)
+    return faces, bcs
+
+
+def load_landmarks(meas_definition_path, meas_vertices_path):
+    """body_measurements.py:33-76 -> dict name -> (face_idx, bc f32[3])."""
+    with open(meas_definition_path) as f:
+        defs = yaml.safe_load(f)
+    with open(meas_vertices_path) as f:
+        verts = yaml.safe_load(f)
+    pick = lambda n: (int(verts[n]['face_idx']), np.asarray(verts[n]['bc'], f32))
+    return {
+        'head_top': pick('HeadTop'), 'left_heel': pick('HeelLeft'),
+        'chest': pick(defs['CW_p'][0]), 'waist': pick(defs['BW_p'][0]),
+        'hips': pick(defs['IW_p'][0]),
+    }
+
+
+def plane_triangles(height):
+    """_get_plane_at_heights (body_measurements.py:86-97): [B,2,3,3]."""
+    B = height.shape[0]
+    verts = np.tile(np.array([[-1., 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], f32), (B, 1, 1))
+    verts[:, :, 1] = height.reshape(B, 1)
+    faces = np.array([[0, 1, 2], [0, 2, 3]])
+    return verts[:, faces]
+
+
+def compute_mass(tris):
+    """body_measurements.py:201-215."""
+    x, y, z = tris[..., 0], tris[..., 1], tris[..., 2]
+    vol = (-x[:, :, 2] * y[:, :, 1] * z[:, :, 0] + x[:, :, 1] * y[:, :, 2] * z[:, :, 0] +
+           x[:, :, 2] * y[:, :, 0] * z[:, :, 1] - x[:, :, 0] * y[:, :, 2] * z[:, :, 1] -
+           x[:, :, 1] * y[:, :, 0] * z[:, :, 2] + x[:, :, 0] * y[:, :, 1] * z[:, :, 2])
+    vol = np.abs(vol.astype(f32).sum(axis=1, dtype=f32)) / f32(6.0)
+    return (vol * f32(DENSITY)).astype(f32)
+
+
+def compute_height(tris, lm):
+    """body_measurements.py:182-199."""
+    (hf, hb), (lf, lb) = lm['head_top'], lm['left_heel']
+    head = (tris[:, hf] * hb.reshape(1, 3, 1)).sum(axis=1, dtype=f32)
+    heel = (tris[:, lf] * lb.reshape(1, 3, 1)).sum(axis=1, dtype=f32)
+    return np.abs(head[:, 1] - heel[:, 1]).astype(f32)
+
+
+def hull_perimeter(points):
+    """body_measurements.py:160-179: 2-D hull over (x, z), perimeter summed in 3-D.
+    points: [N,3] f32 (every intersection point appears twice, as in the reference)."""
+    from scipy.spatial import ConvexHull
+    hull = ConvexHull(points[:, [0, 2]])
+    seg = points[hull.simplices.reshape(-1)].reshape(-1, 2, 3)
+    d = (seg[:, 1] - seg[:, 0]).astype(f32)
+    return np.sqrt((d * d).sum(axis=-1, dtype=f32)).sum(dtype=f32)
+
+
+def compute_peripheries(tris, lm, max_collisions=256, return_points=False):
+    """body_measurements.py:99-180."""
+    B = tris.shape[0]
+    out = {}
+    for name in ('chest', 'waist', 'hips'):
+        fi, bc = lm[name]
+        vertex = (tris[:, fi] * bc.reshape(1, 3, 1)).sum(axis=1, dtype=f32)
+        planes = plane_triangles(vertex[:, 1])
+        faces, bcs = mesh_to_mesh_forward(planes, tris, max_collisions)
+        vals, pts_all = [], []
+        for b in range(B):
+            valid = np.where(faces[b] > 0)[0]            # drops face 0 too (:161)
+            sel = tris[b][faces[b][valid]]               # n,3,3
+            pts = (sel[:, None] * bcs[b][valid][:, :, :, None]).sum(axis=-2, dtype=f32)  # n,2,3
+            pts = pts.reshape(-1, 3).astype(f32)
+            vals.append(hull_perimeter(pts))
+            pts_all.append(pts)
+        out[name] = np.asarray(vals, f32)
+        if return_points:
+            out[name + '_points'] = pts_all
+            out[name + '_height'] = vertex[:, 1]
+    return out
+
+
+def body_measurements(tris, lm, max_collisions=256):
+    """BodyMeasurements.forward (body_measurements.py:217-246) -> dict of f32 [B]."""
+    tris = np.ascontiguousarray(tris, f32)
+    out = {'mass': compute_mass(tris), 'height': compute_height(tris, lm)}
+    out.update(compute_peripheries(tris, lm, max_collisions))
+    return out

@@ -1,0 +1,221 @@
+"""Generates the golden vectors under tests/golden/ from the REAL reference code.
+
+Run in the build container only (needs the read-only reference tree at /root/reference):
+
+    python tests/golden/make_golden.py
+
+What is recorded (all float32 unless noted):
+  img_00_pins.npz      arrays copied from the reference's shipped SHAPY_A output
+                       samples/shapy_fit_for_virtual_measurements/img_00.npz (+ the five
+                       measurement values stored inside it)
+  measure_golden.npz   reference BodyMeasurements (real consumer code,
+                       body_measurements.py; the CUDA-only intersection op replaced by the
+                       brute-force oracle) on the 4 real SHAPY meshes shipped with the repo
+  ops_golden.npz       reference batch_rodrigues / ContinuousRotReprDecoder / SMPLX.forward /
+                       WeakPerspectiveCamera on seeded inputs + the synthetic SMPL-X model
+  hrnet_golden.npz     reference HighResolutionNet (CPU) on seeded weights + images
+  regressor_golden.npz reference SMPLXRegressor.forward (CPU), B=4 @224, seeded everything
+
+Weights/images/SMPL-X buffers are *not* stored: they are regenerated bit-identically from
+their seeds by shapy_amd/utils/synthetic.py (numpy PCG64).
+"""
+import os
+import os.path as osp
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = osp.dirname(osp.abspath(__file__))
+ROOT = osp.dirname(osp.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_loader                                    # noqa: E402
+from oracle import measure as omeasure               # noqa: E402
+from shapy_amd.config import merge_config            # noqa: E402
+from shapy_amd.utils import synthetic as syn         # noqa: E402
+
+REF = ref_loader.REF_ROOT
+SUB = 7   # vertex subsampling stride for stored meshes
+
+
+def checksums(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+def main():
+    torch.set_num_threads(8)
+    ns = ref_loader.load_reference(intersect_fn=omeasure.mesh_to_mesh_forward)
+    data_dir = osp.join(ROOT, 'shapy_amd', 'data')
+    meas_def = osp.join(data_dir, 'measurement_defitions.yaml')
+    meas_vert = osp.join(data_dir, 'smplx_measurements.yaml')
+
+    # ---------------- img_00 pins ----------------
+    import pickle, io
+
+    class CPUUnpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module == 'torch.storage' and name == '_load_from_bytes':
+                return lambda b: torch.load(io.BytesIO(b), map_location='cpu')
+            return super().find_class(module, name)
+
+    src = osp.join(REF, 'samples/shapy_fit_for_virtual_measurements/img_00.npz')
+    d = np.load(src, allow_pickle=True)
+    pins = {k: d[k] for k in ('joints', 'global_rot', 'raw_global_rot', 'body_pose',
+                              'raw_body_pose', 'betas', 'camera', 'proj_joints')}
+    # the measurements entry is a pickled dict of CUDA tensors
+    import zipfile
+    with zipfile.ZipFile(src) as z:
+        raw = z.read('measurements.npy')
+    bio = io.BytesIO(raw)
+    np.lib.format.read_magic(bio)
+    np.lib.format.read_array_header_1_0(bio)
+    meas = CPUUnpickler(bio).load()
+    if isinstance(meas, np.ndarray):
+        meas = meas.item()
+    for k, v in meas.items():
+        pins['meas_' + k] = np.asarray(v.detach().cpu().numpy(), np.float32).reshape(-1)
+        print('shipped', k, pins['meas_' + k])
+    np.savez(osp.join(HERE, 'img_00_pins.npz'), **pins)
+
+    # ---------------- measurements on the 4 real meshes ----------------
+    faces, meshes = syn.load_topology()
+    tris = torch.from_numpy(np.ascontiguousarray(meshes[:, faces.astype(np.int64)]))  # 4,F,3,3
+    bm = ns.body_measurements.BodyMeasurements(
+        {'meas_definition_path': meas_def, 'meas_vertices_path': meas_vert})
+    out = bm(tris)['measurements']
+    mg = {k: out[k]['tensor'].numpy().astype(np.float32) for k in
+          ('mass', 'height', 'chest', 'waist', 'hips')}
+    for k in mg:
+        print('ref BodyMeasurements', k, mg[k])
+    for k in ('chest', 'waist', 'hips'):
+        mg[k + '_plane_height'] = out[k]['plane_height'].numpy()
+        mg[k + '_num_points'] = np.array([len(p) for p in out[k]['valid_points']])
+    np.savez(osp.join(HERE, 'measure_golden.npz'), **mg)
+
+    # ---------------- standalone ops ----------------
+    model_folder = '/tmp/shapy_synth_models'
+    syn.write_synthetic_smplx(model_folder, 0)
+    r = syn.rng_for(0, 'ops')
+    og = {}
+    aa = (r.standard_normal((32, 3)) * 1.2).astype(np.float32)
+    aa[0] = 0
+    aa[1] = [1e-9, 0, 0]
+    og['rodrigues_in'] = aa
+    og['rodrigues_out'] = ns.rotation_utils.batch_rodrigues(torch.from_numpy(aa)).numpy()
+    x6 = r.standard_normal((5, 22 * 6)).astype(np.float32)
+    og['cont6d_in'] = x6
+    og['cont6d_out'] = ns.pose_utils.ContinuousRotReprDecoder(22)(torch.from_numpy(x6)).numpy()
+
+    cfg = merge_config([osp.join(ROOT, 'configs/b2a_expose_hrnet_demo.yaml')], [
+        f'body_model.model_folder={model_folder}',
+        'network.smplx.backbone.hrnet.pretrained_path=',
+        f'network.smplx.meas_definition_path={meas_def}',
+        f'network.smplx.meas_vertices_path={meas_vert}',
+    ])
+    smplx = ns.body_models.SMPLX(osp.join(model_folder, 'smplx'), **cfg.body_model.smplx)
+    B = 4
+    betas = r.standard_normal((B, 10)).astype(np.float32)
+    ident6 = np.tile(np.array([1, 0, 0, 1, 0, 0], np.float32), 22)
+    pose6 = (ident6[None] + 0.3 * r.standard_normal((B, 132))).astype(np.float32)
+    # make one body turn its head far enough to exercise the dynamic-landmark LUT clamp
+    rot = ns.pose_utils.ContinuousRotReprDecoder(22)(torch.from_numpy(pose6))
+    og['smplx_betas'] = betas
+    og['smplx_pose6d'] = pose6
+    with torch.no_grad():
+        so = smplx(global_rot=rot[:, :1], body_pose=rot[:, 1:], betas=torch.from_numpy(betas),
+                   get_skin=True, return_shaped=True)
+    og['smplx_joints'] = so['joints']._t.numpy()
+    og['smplx_vertices_sub'] = so['vertices'].numpy()[:, ::SUB]
+    og['smplx_v_shaped_sub'] = so['v_shaped'].numpy()[:, ::SUB]
+    og['smplx_vertices_cs'] = checksums(so['vertices'])
+    og['smplx_v_shaped_cs'] = checksums(so['v_shaped'])
+    cam = r.standard_normal((B, 3)).astype(np.float32)
+    og['cam_in'] = cam
+    scale = torch.nn.functional.softplus(torch.from_numpy(cam[:, :1]))
+    og['cam_proj'] = ns.camera.WeakPerspectiveCamera()(
+        so['joints']._t, scale=scale, translation=torch.from_numpy(cam[:, 1:3])).numpy()
+    np.savez(osp.join(HERE, 'ops_golden.npz'), **og)
+
+    # ---------------- full regressor / HRNet ----------------
+    net = ns.body_heads.BODY_HEAD_REGISTRY['SMPLXRegressor'](
+        cfg.body_model, network_cfg=cfg.network.smplx, loss_cfg=cfg.losses.body)
+    net.eval()
+    syn.fill_module_synthetic(net, 0)
+    sd_keys = sorted((k, tuple(v.shape)) for k, v in net.state_dict().items())
+    with open(osp.join(HERE, 'state_dict_keys.txt'), 'w') as f:
+        for k, s in sd_keys:
+            f.write(f'{k} {list(s)}\n')
+
+    hg = {}
+    stage_stats = {}
+
+    def hook(name):
+        def f(m, i, o):
+            if torch.is_tensor(o):
+                stage_stats[name] = checksums(o)
+            elif isinstance(o, (list, tuple)):
+                for q, t in enumerate(o):
+                    stage_stats[f'{name}.{q}'] = checksums(t)
+        return f
+    for n, m in net.backbone.named_modules():
+        if n in ('bn1', 'bn2', 'layer1', 'stage2', 'stage3', 'stage4', 'subsample_4',
+                 'subsample_3', 'subsample_2', 'conv_layers', 'stage3.0', 'stage4.0'):
+            m.register_forward_hook(hook(n))
+    with torch.no_grad():
+        for tag, (b, s) in {'b2_64': (2, 64), 'b1_224': (1, 224), 'b3_96': (3, 96)}.items():
+            x = torch.from_numpy(syn.synthetic_images(b, s, 0))
+            t0 = time.time()
+            feat = net.backbone(x)['concat']
+            print(tag, 'hrnet fwd', time.time() - t0, 's; feat std', feat.std().item())
+            hg[tag] = feat.numpy()
+            for k, v in stage_stats.items():
+                hg[f'{tag}.cs.{k}'] = v
+        # input sensitivity (documents that the test is not vacuous)
+        x = torch.from_numpy(syn.synthetic_images(2, 64, 0))
+        f2 = net.backbone(x)['concat']
+        print('feature diff between two images / std:',
+              ((f2[0] - f2[1]).std() / f2.std()).item())
+    np.savez(osp.join(HERE, 'hrnet_golden.npz'), **hg)
+
+    rg = {}
+    x = torch.from_numpy(syn.synthetic_images(4, 224, 0))
+    with torch.no_grad():
+        t0 = time.time()
+        out = net(x, None)
+        print('full forward B=4', time.time() - t0, 's')
+    rg['features'] = out['features'].numpy()
+    for i in range(3):
+        st = out[f'stage_{i:02d}']
+        rg[f'stage{i}_betas'] = st['betas'].numpy()
+        rg[f'stage{i}_raw_body_pose'] = st['raw_body_pose'].numpy()
+        rg[f'stage{i}_raw_global_rot'] = st['raw_global_rot'].numpy()
+        rg[f'stage{i}_camera'] = st['camera'].numpy()
+    st = out['stage_02']
+    rg['global_rot'] = st['global_rot'].numpy()
+    rg['body_pose'] = st['body_pose'].numpy()
+    rg['joints'] = st['joints']._t.numpy()
+    rg['vertices_sub'] = st['vertices'].numpy()[:, ::SUB]
+    rg['v_shaped_sub'] = st['v_shaped'].numpy()[:, ::SUB]
+    rg['vertices_cs'] = checksums(st['vertices'])
+    rg['v_shaped_cs'] = checksums(st['v_shaped'])
+    rg['proj_joints'] = out['proj_joints']._t.numpy() if hasattr(out['proj_joints'], '_t') \
+        else out['proj_joints'].numpy()
+    rg['cam_scale'] = out['camera_parameters'].scale.numpy()
+    rg['stage_keys'] = np.array(sorted(st.keys()))
+    rg['out_keys'] = np.array(sorted(str(k) for k in out.keys()))
+    for k, v in out['measurements'].items():
+        rg['meas_' + k] = v.numpy().astype(np.float32)
+        print('regressor measurement', k, rg['meas_' + k])
+    np.savez(osp.join(HERE, 'regressor_golden.npz'), **rg)
+    print('stage_02 keys:', sorted(st.keys()))
+    print('out keys:', sorted(str(k) for k in out.keys()))
+    for f in sorted(os.listdir(HERE)):
+        print(f, osp.getsize(osp.join(HERE, f)))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,141 @@
+"""The CPU oracle against the golden vectors produced by the REAL reference
+(tests/golden/make_golden.py) and against the reference's shipped SHAPY_A sample."""
+import os.path as osp
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import body_np, hrnet_torch, measure
+from shapy_amd.utils import synthetic as syn
+
+DATA = osp.join(osp.dirname(osp.dirname(osp.abspath(__file__))), 'shapy_amd', 'data')
+LM = measure.load_landmarks(osp.join(DATA, 'measurement_defitions.yaml'),
+                            osp.join(DATA, 'smplx_measurements.yaml'))
+SUB = 7
+
+
+def load(golden_dir, name):
+    return np.load(osp.join(golden_dir, name), allow_pickle=False)
+
+
+# ---- shipped SHAPY_A sample (img_00.npz) ----------------------------------------------
+def test_cont6d_decoder_matches_shipped_sample(golden_dir):
+    g = load(golden_dir, 'img_00_pins.npz')
+    gr = body_np.cont_rot_repr_decode(g['raw_global_rot'][None])[0]
+    bp = body_np.cont_rot_repr_decode(g['raw_body_pose'][None])[0]
+    assert np.abs(gr - g['global_rot']).max() < 2e-7
+    assert np.abs(bp - g['body_pose']).max() < 2e-7
+
+
+def test_camera_projection_matches_shipped_sample(golden_dir):
+    g = load(golden_dir, 'img_00_pins.npz')
+    cam = g['camera'][None]
+    proj = body_np.weak_persp_project(g['joints'][None], body_np.softplus(cam[:, :1]), cam[:, 1:3])
+    assert np.abs(proj[0] - g['proj_joints']).max() < 1e-6
+
+
+def test_measurements_match_shipped_sample(golden_dir):
+    g = load(golden_dir, 'img_00_pins.npz')
+    faces, meshes = syn.load_topology()
+    tris = meshes[:1][:, faces]
+    m = measure.body_measurements(tris, LM)
+    assert m['mass'][0] == pytest.approx(float(g['meas_mass'][0]), abs=1e-4)
+    assert m['height'][0] == pytest.approx(float(g['meas_height'][0]), abs=1e-6)
+    for k in ('chest', 'waist', 'hips'):
+        assert m[k][0] == pytest.approx(float(g['meas_' + k][0]), abs=5e-7), k
+
+
+def test_measurements_match_reference_consumer_on_4_meshes(golden_dir):
+    g = load(golden_dir, 'measure_golden.npz')
+    faces, meshes = syn.load_topology()
+    m = measure.body_measurements(meshes[:, faces], LM)
+    for k in ('mass', 'height', 'chest', 'waist', 'hips'):
+        np.testing.assert_allclose(m[k], g[k], rtol=2e-6, atol=1e-6, err_msg=k)
+
+
+# ---- ops vs the real reference modules -------------------------------------------------
+def test_rodrigues(golden_dir):
+    g = load(golden_dir, 'ops_golden.npz')
+    out = body_np.batch_rodrigues(g['rodrigues_in'])
+    assert np.abs(out - g['rodrigues_out']).max() < 1e-6
+
+
+def test_cont6d(golden_dir):
+    g = load(golden_dir, 'ops_golden.npz')
+    out = body_np.cont_rot_repr_decode(g['cont6d_in'])
+    assert np.abs(out - g['cont6d_out']).max() < 1e-5      # large random inputs: few ulp
+
+
+def test_smplx_forward(golden_dir, synth_smplx):
+    g = load(golden_dir, 'ops_golden.npz')
+    rot = body_np.cont_rot_repr_decode(g['smplx_pose6d'])
+    out = body_np.smplx_forward(synth_smplx, rot[:, :1], rot[:, 1:], g['smplx_betas'])
+    assert np.abs(out['joints'] - g['smplx_joints']).max() < 2e-5
+    assert np.abs(out['vertices'][:, ::SUB] - g['smplx_vertices_sub']).max() < 2e-5
+    assert np.abs(out['v_shaped'][:, ::SUB] - g['smplx_v_shaped_sub']).max() < 1e-6
+    cs = np.array([out['vertices'].astype(np.float64).sum(),
+                   np.abs(out['vertices'].astype(np.float64)).sum()])
+    np.testing.assert_allclose(cs, g['smplx_vertices_cs'][:2], rtol=1e-5)
+    cam = g['cam_in']
+    proj = body_np.weak_persp_project(out['joints'], body_np.softplus(cam[:, :1]), cam[:, 1:3])
+    assert np.abs(proj - g['cam_proj']).max() < 5e-5
+
+
+# ---- HRNet + full regressor ------------------------------------------------------------
+@pytest.fixture(scope='module')
+def hrnet_sd():
+    sd = syn.synthetic_state_dict([('backbone.' + n, s) for n, s in hrnet_torch.state_dict_spec()], 0)
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def test_state_dict_spec_matches_reference(golden_dir):
+    ref = {}
+    with open(osp.join(golden_dir, 'state_dict_keys.txt')) as f:
+        for line in f:
+            k, s = line.strip().split(' ', 1)
+            if k.startswith('backbone.'):
+                ref[k] = tuple(eval(s))
+    mine = {'backbone.' + n: tuple(s) for n, s in hrnet_torch.state_dict_spec()}
+    assert mine == ref
+    assert len(mine) == 1967
+
+
+@pytest.mark.parametrize('tag,b,s', [('b2_64', 2, 64), ('b3_96', 3, 96), ('b1_224', 1, 224)])
+def test_hrnet_oracle_matches_reference(golden_dir, hrnet_sd, tag, b, s):
+    g = load(golden_dir, 'hrnet_golden.npz')
+    x = torch.from_numpy(syn.synthetic_images(b, s, 0))
+    with torch.no_grad():
+        out = hrnet_torch.hrnet_forward(hrnet_sd, x, prefix='backbone.').numpy()
+    assert np.abs(out - g[tag]).max() < 2e-5
+
+
+def test_full_regressor_oracle_matches_reference(golden_dir, hrnet_sd, synth_smplx):
+    g = load(golden_dir, 'regressor_golden.npz')
+    spec = [('regressor.module.layer_000.0.weight', (1024, 2193)),
+            ('regressor.module.layer_000.0.bias', (1024,)),
+            ('regressor.module.layer_001.0.weight', (1024, 1024)),
+            ('regressor.module.layer_001.0.bias', (1024,)),
+            ('regressor.module.output_layer.weight', (145, 1024)),
+            ('regressor.module.output_layer.bias', (145,))]
+    w = syn.synthetic_state_dict(spec, 0)
+    layers = [(w[spec[2 * i][0]], w[spec[2 * i + 1][0]]) for i in range(3)]
+    x = torch.from_numpy(syn.synthetic_images(4, 224, 0))
+    with torch.no_grad():
+        feat = hrnet_torch.hrnet_forward(hrnet_sd, x, prefix='backbone.').numpy()
+    assert np.abs(feat - g['features']).max() < 5e-5
+    out = body_np.regressor_head(feat, layers, synth_smplx)
+    for i in range(3):
+        assert np.abs(out['stages'][i]['betas'] - g[f'stage{i}_betas']).max() < 1e-5
+        assert np.abs(out['stages'][i]['raw_body_pose'] - g[f'stage{i}_raw_body_pose']).max() < 1e-5
+        assert np.abs(out['stages'][i]['camera'] - g[f'stage{i}_camera']).max() < 1e-5
+    last = out['stages'][-1]
+    assert np.abs(last['body_pose'] - g['body_pose']).max() < 1e-5
+    assert np.abs(last['joints'] - g['joints']).max() < 5e-5
+    assert np.abs(last['vertices'][:, ::SUB] - g['vertices_sub']).max() < 5e-5
+    assert np.abs(last['v_shaped'][:, ::SUB] - g['v_shaped_sub']).max() < 1e-5
+    assert np.abs(out['proj_joints'] - g['proj_joints']).max() < 5e-5
+    faces = synth_smplx['f']
+    m = measure.body_measurements(last['v_shaped'][:, faces], LM)
+    for k in ('mass', 'height', 'chest', 'waist', 'hips'):
+        np.testing.assert_allclose(m[k], g['meas_' + k], rtol=1e-4, atol=1e-4, err_msg=k)
