@@ -1,0 +1,197 @@
+"""Headline benchmark: images/sec of the SHAPY hot path (HRNet-W48 + iterative regressor +
+SMPL-X + virtual measurements) on synthetic 224x224 crops, batch 64 per GPU, float32.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full forward of the regressor on one batch that is already resident in HBM
+(BASELINE.json configs[1]: "HRNet-W48 + SMPL-X head, random-init weights, 224x224 bs=64 fp32
+on 1xMI355X"); with N > 1 every rank runs its own shard (weak scaling: 64 images per GPU) and
+the predicted betas are all-gathered with RCCL at the end of every step.
+
+Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
+  roofline      the MFMA roofline of the dominant kernel family (conv_igemm_f32, 330 launches
+                per backbone forward): algorithmic conv FLOPs (2 x 18,466,524,160 MAC per image,
+                SURVEY.md 8d) / time of the backbone call, measured with HIP events on the
+                launch stream inside the timed loop; peak = 157.3 TFLOP/s (f32 MFMA, dense)
+  cpu_baseline  the CPU oracle (torch CPU restatement of the reference, "port") timed on this
+                host's cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import os.path as osp
+import sys
+import time
+
+ROOT = osp.dirname(osp.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+CONV_FLOP_PER_IMAGE_224 = 2 * 18_466_524_160       # SURVEY.md 8(d), counted from the reference
+F32_MFMA_PEAK_TFLOPS = 157.3                       # MI355X_MICROARCH.md, dense f32 MFMA
+
+
+def conv_flop_per_image(net, size):
+    plan = net.backbone._build_plan(size, size)
+    macs = sum(o['Ho'] * o['Wo'] * o['Cout'] * o['Cin'] * o['ksize'] ** 2
+               for o in plan.ops if o['type'] != 2)
+    return 2 * macs
+
+
+def cpu_baseline(batch, size, budget_s=15.0):
+    """Times the CPU oracle (kind 'port') for about `budget_s` seconds of work."""
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+    from shapy_amd.utils import synthetic as syn
+    cores = torch.get_num_threads()
+    b = min(batch, 8)
+    x = syn.synthetic_images(b, size, 1)
+    ge.oracle_forward(x, with_measurements=True)           # warm-up (builds weights, pages in)
+    n, t0 = 0, time.perf_counter()
+    # weights are regenerated inside oracle_forward; time only the forward passes
+    import oracle.hrnet_torch as ht
+    from oracle import body_np, measure
+    sd = syn.synthetic_state_dict([('backbone.' + k, s) for k, s in ht.state_dict_spec()], 0)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    spec = [('regressor.module.layer_000.0.weight', (1024, 2193)),
+            ('regressor.module.layer_000.0.bias', (1024,)),
+            ('regressor.module.layer_001.0.weight', (1024, 1024)),
+            ('regressor.module.layer_001.0.bias', (1024,)),
+            ('regressor.module.output_layer.weight', (145, 1024)),
+            ('regressor.module.output_layer.bias', (145,))]
+    w = syn.synthetic_state_dict(spec, 0)
+    layers = [(w[spec[2 * i][0]], w[spec[2 * i + 1][0]]) for i in range(3)]
+    model = syn.make_synthetic_smplx(0)
+    data = osp.join(ROOT, 'shapy_amd', 'data')
+    lm = measure.load_landmarks(osp.join(data, 'measurement_defitions.yaml'),
+                                osp.join(data, 'smplx_measurements.yaml'))
+    xt = torch.from_numpy(x)
+    t0 = time.perf_counter()
+    while True:
+        with torch.no_grad():
+            feat = ht.hrnet_forward(sd, xt, prefix='backbone.').numpy()
+        out = body_np.regressor_head(feat, layers, model)
+        measure.body_measurements(out['stages'][-1]['v_shaped'][:, model['f']], lm)
+        n += b
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} images ({size}x{size}, batches of {b}) through the CPU oracle '
+                      f'(torch-CPU HRNet + numpy SMPL-X + C intersection + scipy hull) in {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU')
+    ap.add_argument('--size', type=int, default=224)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--single-stream', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from shapy_amd.utils import synthetic as syn
+    from shapy_amd import parallel
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks '
+                         f'(WORLD_SIZE={world})')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', init_method='env://')
+
+    net, _ = ge.make_network(model_folder=f'/tmp/shapy_synth_models_r{local_rank}' if world > 1
+                             else '/tmp/shapy_synth_models')
+    net.backbone.multi_stream = not args.single_stream
+    B = args.batch
+    # distinct synthetic images per rank (global batch = world * B), resident in HBM
+    x = torch.from_numpy(syn.synthetic_images(B, args.size, 100 + rank)).cuda()
+    gatherer = parallel.BetasGatherer(world)
+
+    def step():
+        with torch.no_grad():
+            out = net(x, None)
+            betas = gatherer(out['stage_02']['betas'])
+        return out, betas
+
+    for _ in range(args.warmup):
+        step()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # events around the backbone call are recorded on the launch stream by a forward hook pair
+    idx = {'i': 0}
+    h0 = net.backbone.register_forward_pre_hook(lambda m, a: ev0[idx['i']].record())
+    h1 = net.backbone.register_forward_hook(lambda m, a, o: ev1[idx['i']].record())
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        idx['i'] = i
+        out, betas = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    h0.remove(); h1.remove()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert betas.shape == (world * B, 10)
+
+    backbone_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    flop_img = conv_flop_per_image(net, args.size)
+    achieved = flop_img * B / (backbone_ms * 1e-3) / 1e12
+    if rank == 0:
+        res = {
+            'metric': 'images/sec whole-node (HRNet+SMPL-X fwd), 224x224 bs=64; betas L2 vs CPU',
+            'value': world * B * args.steps / dt,
+            'unit': 'images/sec',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': f'HRNet-W48 + iterative regressor + SMPL-X + virtual '
+                                   f'measurements, random-init weights, {args.size}x{args.size}, '
+                                   f'bs={B} per GPU, fp32 (BASELINE configs[1])',
+                       'global_batch': world * B, 'parallelism': f'dp{world}',
+                       'multi_stream': not args.single_stream},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
+                         'traffic': None,
+                         'kernel': 'conv_igemm_f32_kernel (330 launches per backbone forward)',
+                         'flop_per_launch_group': flop_img * B,
+                         'ms_per_launch_group': backbone_ms},
+        }
+        if not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(B, args.size)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

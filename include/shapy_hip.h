@@ -1,0 +1,211 @@
+/* shapy_hip.h -- C-ABI of the MI355X-native SHAPY hot path (libshapy_hip.so).
+ *
+ * Plain pointers and sizes only: no torch / ATen types cross this boundary.  Every pointer
+ * is DEVICE memory unless its name ends in _host.  Every entry point enqueues its work on
+ * `stream` (a hipStream_t passed as void*; NULL = the default stream), never synchronises
+ * the device and returns 0 on success or a hipError_t / negative SHAPY_E* code.
+ *
+ * What each entry point replaces in the reference (muelea/shapy):
+ *
+ *  shapy_conv2d_f32 / shapy_hrnet_run_f32
+ *      the 331 cuDNN convolutions + eval-mode BatchNorm + ReLU + residual adds + nearest
+ *      upsampling + concat + spatial mean of HighResolutionNet.forward
+ *      (regressor/human_shape/models/backbone/hrnet.py:426-498, :175-193)
+ *  shapy_regressor_affine_f32
+ *      IterativeRegression.forward / MLP.forward
+ *      (regressor/human_shape/models/common/networks.py:536-592, :392-400)
+ *  shapy_smplx_pose_f32, shapy_smplx_skin_f32, shapy_smplx_joints_f32
+ *      ContinuousRotReprDecoder.forward (models/common/pose_utils.py:138-153),
+ *      batch_rodrigues (utils/rotation_utils.py:5-37), lbs() and batch_rigid_transform
+ *      (models/body_models/lbs.py:99-196, :242-295), the landmark code (lbs.py:20-94),
+ *      WeakPerspectiveCamera.forward (models/camera/camera_projection.py:181-213)
+ *  shapy_mesh_to_mesh_f32 (+ _workspace_bytes)
+ *      mesh_mesh_intersect_cuda.mesh_to_mesh_forward
+ *      (mesh-mesh-intersection/src/mesh_mesh_intersect.cpp:36-64,
+ *       src/mesh_mesh_intersect_cuda_op.cu:969-1079 and every kernel it launches)
+ *  shapy_body_measure_f32 (+ _workspace_bytes)
+ *      BodyMeasurements.forward: compute_mass / compute_height / compute_peripheries incl.
+ *      the per-mesh scipy ConvexHull (mesh-mesh-intersection/body_measurements/
+ *      body_measurements.py:99-246)
+ */
+#ifndef SHAPY_HIP_H
+#define SHAPY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHAPY_OK 0
+#define SHAPY_EINVAL (-1)      /* bad argument (shape / alignment / unsupported mode) */
+#define SHAPY_EWORKSPACE (-2)  /* workspace too small */
+
+/* ABI version; bumped whenever a struct below changes. */
+int shapy_abi_version(void);
+/* name of the gfx target the library was built for ("gfx950") */
+const char *shapy_build_arch(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Convolution / GEMM (implicit GEMM on f32 MFMA, NHWC activations, OHWI weights)
+ *
+ *   out[b,ho,wo, out_coff + n] = act( bias[n] + sum_{kh,kw,c} in[b, ho*s-p+kh, wo*s-p+kw, c]
+ *                                                   * wgt[n, kh, kw, c]  (+ res[...]) )
+ * With ups > 1 the value computed for the (low-res) output pixel is written to the ups x ups
+ * block of pixels of an output (and residual) tensor of size [B, Ho*ups, Wo*ups] -- the
+ * conv1x1 + BN + nearest-Upsample + add of an HRNet fuse layer (hrnet.py:125-136,184-191) in
+ * one pass.  BatchNorm is folded into wgt/bias by the host (float64).
+ * A plain GEMM out[M,N] = in[M,K] * wgt[N,K]^T + bias is the case ksize=1, Hi=Wi=Ho=Wo=1,
+ * B=M.  Requirements: Cin % 16 == 0, all pointers 16-byte aligned, in_ld/out_ld/res_ld % 4 == 0
+ * is NOT required (only Cin and in_ld % 4 == 0).
+ * ------------------------------------------------------------------------------------- */
+typedef struct ShapyConv {
+  const float *in;    /* [B, Hi, Wi, in_ld]   (first Cin channels of each pixel are used)   */
+  const float *wgt;   /* [Cout, ksize, ksize, Cin]                                         */
+  const float *bias;  /* [Cout] or NULL                                                    */
+  const float *res;   /* residual, indexed like out (res_ld, res_coff), or NULL; may == out */
+  float *out;         /* [B, Ho*ups, Wo*ups, out_ld]                                       */
+  int32_t B, Hi, Wi, Cin, in_ld;
+  int32_t Ho, Wo, Cout;
+  int32_t ksize, stride, pad;
+  int32_t out_ld, out_coff, res_ld, res_coff;
+  int32_t relu;       /* 1: ReLU after the (residual) add                                  */
+  int32_t ups;        /* 1 = none; 2/4/8 = nearest-upsample scatter                        */
+  int32_t tile;       /* 0 = choose automatically; else a SHAPY_TILE_* id (bench/tuning)   */
+} ShapyConv;
+
+int shapy_conv2d_f32(const ShapyConv *desc_host, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * HRNet op list.  The host (Python) flattens the module tree into `ops`; buffers are
+ * offsets (in floats, per image) into one workspace allocation that is scaled by B.
+ * ------------------------------------------------------------------------------------- */
+enum { SHAPY_OP_CONV = 0, SHAPY_OP_STEM = 1, SHAPY_OP_MEANPOOL = 2 };
+
+typedef struct ShapyOp {
+  int32_t type;
+  int32_t lane;                /* independent branch id (0..3): ops of different lanes between
+                                  two barriers may run concurrently                          */
+  int32_t barrier_before;      /* 1: all lanes must have finished before this op starts     */
+  int32_t Hi, Wi, Cin, in_ld, Ho, Wo, Cout, ksize, stride, pad;
+  int32_t out_ld, out_coff, res_ld, res_coff, relu, ups, tile;
+  int64_t in_off, out_off, res_off;     /* per-image float offsets into the workspace; -1 = none;
+                                            in_off == -2: the network input (STEM)           */
+  int64_t wgt_off, bias_off;            /* float offsets into the weight blob; -1 = none     */
+} ShapyOp;
+
+/* input: [B,3,H,W] NCHW f32 (the reference's layout, iterative_regressor.py:623);
+ * features_out: [B, Cfeat].  workspace must hold B * ws_floats_per_image floats. */
+int shapy_hrnet_run_f32(const ShapyOp *ops_host, int n_ops, const float *weights,
+                        const float *input_nchw, float *workspace, int64_t ws_floats_per_image,
+                        float *features_out, int B, int H, int W, int multi_stream,
+                        void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Iterative regressor, affine-collapsed form.  The SHAPY_A MLP has no activation and no
+ * normalisation (configs/b2a_expose_hrnet_demo.yaml:200-207), so each stage is
+ *     p_i = p_{i-1} + Wf * feat + Wp * p_{i-1} + b
+ * with Wf [P, F], Wp [P, P], b [P] collapsed from the three Linear layers by the host in
+ * float64.  params_out: [num_stages, B, P].
+ * ------------------------------------------------------------------------------------- */
+int shapy_regressor_affine_f32(const float *features, const float *Wf, const float *Wp,
+                               const float *bias, const float *mean_param, float *params_out,
+                               int B, int F, int P, int num_stages, int cond_per_body,
+                               void *stream);
+/* mean_param: [P] (cond_per_body = 0) or a per-body initial condition [B,P] (= 1), the
+ * `cond` argument of IterativeRegression.forward (networks.py:536-566). */
+
+/* ---------------------------------------------------------------------------------------
+ * SMPL-X
+ * ------------------------------------------------------------------------------------- */
+typedef struct ShapySmplxModel {
+  int32_t V, J, NB;             /* vertices, joints (55), shape comps incl. expression      */
+  int32_t P;                    /* pose-feature dim = (J-1)*9, Ppad = round_up(P,16)         */
+  int32_t Ppad, NBpad;          /* K paddings of the two GEMMs                               */
+  int32_t n_static_lmk, n_dyn_lmk, n_dyn_rows, n_neck;
+  const int32_t *parents;       /* [J], parents[0] = -1                                      */
+  const float *J_template;      /* [J,3]      = J_regressor * v_template      (float64 fold) */
+  const float *J_shapedirs;     /* [J,3,NB]   = J_regressor * shapedirs                      */
+  const float *v_template;      /* [V*3]                                                     */
+  const float *shapedirs_t;     /* [V*3 (row-padded to x96), NBpad]  K-contiguous            */
+  const float *posedirs_t;      /* [V*3 (row-padded to x96), Ppad]   K-contiguous            */
+  const float *lbs_weights_t;   /* [J, V]                                                    */
+  const int32_t *faces;         /* [F,3]                                                     */
+  const int32_t *lmk_faces_idx;         /* [n_static_lmk]                                    */
+  const float *lmk_bary;                /* [n_static_lmk,3]                                  */
+  const int32_t *dyn_lmk_faces_idx;     /* [n_dyn_rows, n_dyn_lmk]                           */
+  const float *dyn_lmk_bary;            /* [n_dyn_rows, n_dyn_lmk, 3]                        */
+  const int32_t *neck_kin_chain;        /* [n_neck]                                          */
+} ShapySmplxModel;
+
+enum { SHAPY_POSE_ROTMAT = 0, SHAPY_POSE_CONT6D = 1, SHAPY_POSE_AXIS_ANGLE = 2 };
+
+/* Per body: decode the pose (n_pose joints given, the remaining joints are identity), regress
+ * the rest joints from the shape coefficients, run the kinematic chain.
+ *   pose:        [B, n_pose, 6] (CONT6D, interleaved [a1x,a2x,a1y,a2y,a1z,a2z]) | [B,n_pose,3]
+ *                (AXIS_ANGLE) | [B,n_pose,3,3] (ROTMAT)
+ *   coeffs:      [B, NBpad]  shape (+expression) coefficients, zero padded
+ *   rot_out:     [B, J, 3, 3]   pose_feat_out: [B, Ppad]   A_out: [B, J, 12] (3x4 rel. transforms)
+ *   joints_out:  [B, J, 3] posed joints     dyn_row_out: [B] int32 LUT row (lbs.py:33-41)   */
+int shapy_smplx_pose_f32(const ShapySmplxModel *model_host, const float *pose, int pose_type,
+                         int n_pose, const float *coeffs, float *rot_out, float *pose_feat_out,
+                         float *A_out, float *joints_out, int32_t *dyn_row_out, int B,
+                         void *stream);
+
+/* Stand-alone decoders: [n,6] (CONT6D, pose_utils.py:138-153) or [n,3] (AXIS_ANGLE,
+ * rotation_utils.py:5-37) -> [n,3,3]. */
+int shapy_pose_decode_f32(const float *pose, int pose_type, float *rot_out, int64_t n,
+                          void *stream);
+
+/* WeakPerspectiveCamera.forward (camera_projection.py:181-213): points [B,N,3], scale [B],
+ * translation [B,2] -> out [B,N,2]. */
+int shapy_weak_persp_project_f32(const float *points, const float *scale,
+                                 const float *translation, float *out, int B, int N,
+                                 int scale_first, void *stream);
+
+/* vertices[b,v,:] = (sum_j W[v,j] A[b,j]) * [v_posed[b,v,:]; 1]   (lbs.py:187-190) */
+int shapy_smplx_skin_f32(const ShapySmplxModel *model_host, const float *A, const float *v_posed,
+                         float *vertices_out, int B, void *stream);
+
+/* Extra joint regressor (body_models.py:738-744): out[b,j,:] = sum_v regressor[j,v] *
+ * vertices[b,v,:];  regressor [Jn,V], vertices [B,V,3], out [B,Jn,3]. */
+int shapy_joint_regress_f32(const float *regressor, const float *vertices, float *out, int B,
+                            int V, int Jn, void *stream);
+
+/* joints_out[b] = cat(posed joints [J], static landmarks, dynamic landmarks) [B, n_out, 3];
+ * proj_out = softplus(cam[:,0]) * (joints_xy + cam[:,1:3])  [B, n_out, 2] (NULL to skip). */
+int shapy_smplx_joints_f32(const ShapySmplxModel *model_host, const float *posed_joints,
+                           const float *vertices, const int32_t *dyn_row, const float *camera,
+                           float *joints_out, float *proj_out, float *cam_scale_out, int B,
+                           int use_face_contour, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Mesh-mesh intersection (the reference's operator boundary)
+ *   query  [B,Q,3,3] f32, target [B,F,3,3] f32
+ *   faces_out int64 [B, Q*max_coll] (-1 = empty), bcs_out f32 [B, Q*max_coll, 2, 3] (0 = empty)
+ * Slot order inside a query triangle's max_coll slots is ascending target-face index
+ * (the reference's is BVH traversal order, unspecified).  Hits beyond max_coll are dropped
+ * and counted in *overflow_out (int32 device counter, may be NULL); the reference writes
+ * out of bounds in that case (.cu:551,565).
+ * ------------------------------------------------------------------------------------- */
+size_t shapy_mesh_to_mesh_workspace_bytes(int B, int Q, int F, int max_coll);
+int shapy_mesh_to_mesh_f32(const float *query, const float *target, int B, int Q, int F,
+                           int max_coll, int64_t *faces_out, float *bcs_out, void *workspace,
+                           size_t workspace_bytes, int32_t *overflow_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused virtual measurements: mass, height, chest, waist, hips from v_shaped + faces.
+ *   lm_face[5], lm_bary[5][3]: HeadTop, HeelLeft, chest, waist, hips landmarks (host memory)
+ *   out: [B,5] f32 = mass(kg), height, chest, waist, hips (m)
+ * ------------------------------------------------------------------------------------- */
+size_t shapy_body_measure_workspace_bytes(int B, int F, int max_coll);
+int shapy_body_measure_f32(const float *v_shaped, const int32_t *faces, int B, int V, int F,
+                           const int32_t *lm_face_host, const float *lm_bary_host, int max_coll,
+                           float *out, void *workspace, size_t workspace_bytes,
+                           int32_t *overflow_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHAPY_HIP_H */

@@ -1,0 +1,440 @@
+// Regressor head + SMPL-X kernels (everything between the backbone features and the posed
+// body).  One workgroup per body for the small per-body stages; the two blend-shape GEMMs run
+// on the MFMA conv/GEMM kernel (conv_igemm.hip) and are issued by the host.
+#include "common.h"
+
+namespace shapy {
+
+// ------------------------------------------------------------------------------------------
+// IterativeRegression (networks.py:536-592) with the affine-collapsed MLP:
+//   t = Wf feat + b ;  p_s = p_{s-1} + t + Wp p_{s-1}
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void regressor_affine_kernel(
+    const float *__restrict__ feat, const float *__restrict__ Wf, const float *__restrict__ Wp,
+    const float *__restrict__ bias, const float *__restrict__ mean, float *__restrict__ out, int B,
+    int F, int P, int S, int mean_stride) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float *t = sm;            // [P]
+  float *pa = sm + P;       // [P]
+  float *pb = sm + 2 * P;   // [P]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *x = feat + (long)b * F;
+  for (int r = wave; r < P; r += 4) {
+    const float *w = Wf + (long)r * F;
+    float s = 0.f;
+    for (int k = lane * 4; k < F; k += 256) {
+      const float4 wv = *reinterpret_cast<const float4 *>(w + k);
+      const float4 xv = *reinterpret_cast<const float4 *>(x + k);
+      s = fmaf(wv.x, xv.x, s); s = fmaf(wv.y, xv.y, s);
+      s = fmaf(wv.z, xv.z, s); s = fmaf(wv.w, xv.w, s);
+    }
+    s = wave_reduce_sum(s);
+    if (lane == 0) t[r] = s + bias[r];
+  }
+  for (int i = tid; i < P; i += 256) pa[i] = mean[(long)b * mean_stride + i];
+  __syncthreads();
+  float *prev = pa, *next = pb;
+  for (int s = 0; s < S; ++s) {
+    for (int i = tid; i < P; i += 256) {
+      const float *w = Wp + (long)i * P;
+      float acc = 0.f;
+      for (int j = 0; j < P; ++j) acc = fmaf(w[j], prev[j], acc);
+      const float v = prev[i] + (t[i] + acc);
+      next[i] = v;
+      out[((long)s * B + b) * P + i] = v;
+    }
+    __syncthreads();
+    float *tmp = prev; prev = next; next = tmp;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pose decode + joint regression + kinematic chain, one 64-lane workgroup per body
+// ------------------------------------------------------------------------------------------
+struct PoseK {
+  const int32_t *parents, *neck;
+  const float *Jt, *Js, *pose, *coeffs;
+  float *rot, *pf, *A, *joints;
+  int32_t *dyn_row;
+  int J, NB, NBpad, P, Ppad, n_pose, pose_type, n_neck, n_dyn_rows;
+};
+
+__device__ __forceinline__ void mat3_mul(const float *a, const float *b, float *c) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      c[i * 3 + j] = a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j] + a[i * 3 + 2] * b[2 * 3 + j];
+}
+
+__global__ __launch_bounds__(64) void smplx_pose_kernel(PoseK k) {
+  __shared__ float R[64 * 9];
+  __shared__ float Jl[64 * 3];
+  __shared__ float G[64 * 12];
+  const int b = blockIdx.x, j = threadIdx.x;
+  if (j < k.J) {
+    float r[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+    if (j < k.n_pose) {
+      if (k.pose_type == SHAPY_POSE_CONT6D) {
+        // ContinuousRotReprDecoder.forward (pose_utils.py:138-153): x viewed as (3,2)
+        const float *x = k.pose + ((long)b * k.n_pose + j) * 6;
+        const float a1x = x[0], a2x = x[1], a1y = x[2], a2y = x[3], a1z = x[4], a2z = x[5];
+        float n1 = sqrtf(a1x * a1x + a1y * a1y + a1z * a1z);
+        n1 = fmaxf(n1, 1e-12f);
+        const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+        const float d = b1x * a2x + b1y * a2y + b1z * a2z;
+        const float cx = a2x - d * b1x, cy = a2y - d * b1y, cz = a2z - d * b1z;
+        float n2 = sqrtf(cx * cx + cy * cy + cz * cz);
+        n2 = fmaxf(n2, 1e-12f);
+        const float b2x = cx / n2, b2y = cy / n2, b2z = cz / n2;
+        const float b3x = b1y * b2z - b1z * b2y, b3y = b1z * b2x - b1x * b2z,
+                    b3z = b1x * b2y - b1y * b2x;
+        r[0] = b1x; r[1] = b2x; r[2] = b3x;
+        r[3] = b1y; r[4] = b2y; r[5] = b3y;
+        r[6] = b1z; r[7] = b2z; r[8] = b3z;
+      } else if (k.pose_type == SHAPY_POSE_AXIS_ANGLE) {
+        // batch_rodrigues (rotation_utils.py:5-37): eps added to the vector before the norm
+        const float *x = k.pose + ((long)b * k.n_pose + j) * 3;
+        const float ex = x[0] + 1e-8f, ey = x[1] + 1e-8f, ez = x[2] + 1e-8f;
+        const float ang = sqrtf(ex * ex + ey * ey + ez * ez);
+        const float rx = x[0] / ang, ry = x[1] / ang, rz = x[2] / ang;
+        const float c = cosf(ang), s = sinf(ang), oc = 1.f - c;
+        // K = [0 -rz ry; rz 0 -rx; -ry rx 0];  R = I + s K + (1-c) K K
+        const float K[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
+        float KK[9];
+        mat3_mul(K, K, KK);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r[i] = ((i % 4 == 0) ? 1.f : 0.f) + s * K[i] + oc * KK[i];
+      } else {
+        const float *x = k.pose + ((long)b * k.n_pose + j) * 9;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r[i] = x[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      R[j * 9 + i] = r[i];
+      k.rot[((long)b * k.J + j) * 9 + i] = r[i];
+    }
+    // rest joints: J = J_template + J_shapedirs . coeffs   (== J_regressor (v_template + S c))
+    const float *c = k.coeffs + (long)b * k.NBpad;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float *js = k.Js + ((long)j * 3 + a) * k.NB;
+      float s = 0.f;
+      for (int l = 0; l < k.NB; ++l) s = fmaf(js[l], c[l], s);
+      Jl[j * 3 + a] = k.Jt[j * 3 + a] + s;
+    }
+    // pose feature (lbs.py:176): (R[1:] - I) flattened
+    if (j >= 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+        k.pf[(long)b * k.Ppad + (j - 1) * 9 + i] = r[i] - ((i % 4 == 0) ? 1.f : 0.f);
+    }
+  }
+  for (int i = k.P + j; i < k.Ppad; i += 64) k.pf[(long)b * k.Ppad + i] = 0.f;
+  __syncthreads();
+  if (j == 0) {
+    // batch_rigid_transform (lbs.py:242-295): G_i = G_parent * [R_i | J_i - J_parent]
+#pragma unroll
+    for (int i = 0; i < 9; ++i) G[(i / 3) * 4 + (i % 3)] = R[i];
+    G[3] = Jl[0]; G[7] = Jl[1]; G[11] = Jl[2];
+    for (int i = 1; i < k.J; ++i) {
+      const int pa = k.parents[i];
+      const float *Gp = G + pa * 12;
+      const float *Ri = R + i * 9;
+      const float rel[3] = {Jl[i * 3] - Jl[pa * 3], Jl[i * 3 + 1] - Jl[pa * 3 + 1],
+                            Jl[i * 3 + 2] - Jl[pa * 3 + 2]};
+      float *Gi = G + i * 12;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          Gi[r * 4 + c] = Gp[r * 4 + 0] * Ri[0 * 3 + c] + Gp[r * 4 + 1] * Ri[1 * 3 + c] +
+                          Gp[r * 4 + 2] * Ri[2 * 3 + c];
+        Gi[r * 4 + 3] = Gp[r * 4 + 0] * rel[0] + Gp[r * 4 + 1] * rel[1] + Gp[r * 4 + 2] * rel[2] +
+                        Gp[r * 4 + 3];
+      }
+    }
+    // dynamic-landmark LUT row (lbs.py:28-41): rel = R[c0] (R[c1] (... I)), applied in order
+    if (k.dyn_row) {
+      float rel[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, tmp[9];
+      for (int q = 0; q < k.n_neck; ++q) {
+        mat3_mul(R + k.neck[q] * 9, rel, tmp);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rel[i] = tmp[i];
+      }
+      const float sy = sqrtf(rel[0] * rel[0] + rel[3] * rel[3]);
+      const float ang = -atan2f(-rel[6], sy) * 180.0f / 3.14159265358979323846f;
+      int y = (int)rintf(fminf(ang, 39.f));
+      if (y < 0) y = (y < -39) ? 78 : 39 - y;
+      if (y > k.n_dyn_rows - 1) y = k.n_dyn_rows - 1;
+      k.dyn_row[b] = y;
+    }
+  }
+  __syncthreads();
+  if (j < k.J) {
+    const float *Gj = G + j * 12;
+    float *Ao = k.A + ((long)b * k.J + j) * 12;
+    const float jx = Jl[j * 3], jy = Jl[j * 3 + 1], jz = Jl[j * 3 + 2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      Ao[r * 4 + 0] = Gj[r * 4 + 0];
+      Ao[r * 4 + 1] = Gj[r * 4 + 1];
+      Ao[r * 4 + 2] = Gj[r * 4 + 2];
+      Ao[r * 4 + 3] = Gj[r * 4 + 3] - (Gj[r * 4 + 0] * jx + Gj[r * 4 + 1] * jy + Gj[r * 4 + 2] * jz);
+      k.joints[((long)b * k.J + j) * 3 + r] = Gj[r * 4 + 3];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// skinning (lbs.py:187-190): one thread per (body, vertex); A[b] staged in LDS
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void smplx_skin_kernel(const float *__restrict__ Wt,
+                                                         const float *__restrict__ A,
+                                                         const float *__restrict__ v_posed,
+                                                         float *__restrict__ out, int V, int J) {
+  __shared__ float As[64 * 12];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < J * 12; i += 256) As[i] = A[(long)b * J * 12 + i];
+  __syncthreads();
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  float T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = 0.f;
+  for (int j = 0; j < J; ++j) {
+    const float w = Wt[(long)j * V + v];
+    const float *a = As + j * 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = fmaf(w, a[i], T[i]);
+  }
+  const float *p = v_posed + ((long)b * V + v) * 3;
+  const float x = p[0], y = p[1], z = p[2];
+  float *o = out + ((long)b * V + v) * 3;
+  o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+  o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+  o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+}
+
+// ------------------------------------------------------------------------------------------
+// output keypoints: posed joints ++ landmarks (lbs.py:52-94) and weak-perspective projection
+// (camera_projection.py:181-213, iterative_regressor.py:714-733)
+// ------------------------------------------------------------------------------------------
+struct JointsK {
+  const int32_t *faces, *lmk_idx, *dyn_idx, *dyn_row;
+  const float *lmk_bc, *dyn_bc, *posed, *verts, *cam;
+  float *joints, *proj, *scale;
+  int J, V, n_static, n_dyn, n_out;
+};
+
+__global__ __launch_bounds__(128) void smplx_joints_kernel(JointsK k) {
+  const int b = blockIdx.x;
+  float s = 1.f, tx = 0.f, ty = 0.f;
+  if (k.cam) {
+    const float c0 = k.cam[b * 3];
+    s = c0 > 20.f ? c0 : log1pf(expf(c0));   // F.softplus (beta 1, threshold 20)
+    tx = k.cam[b * 3 + 1];
+    ty = k.cam[b * 3 + 2];
+    if (threadIdx.x == 0 && k.scale) k.scale[b] = s;
+  }
+  for (int i = threadIdx.x; i < k.n_out; i += 128) {
+    float x, y, z;
+    if (i < k.J) {
+      const float *p = k.posed + ((long)b * k.J + i) * 3;
+      x = p[0]; y = p[1]; z = p[2];
+    } else {
+      const int l = i - k.J;
+      int f;
+      const float *bc;
+      if (l < k.n_static) {
+        f = k.lmk_idx[l];
+        bc = k.lmk_bc + l * 3;
+      } else {
+        const int row = k.dyn_row[b];
+        f = k.dyn_idx[row * k.n_dyn + (l - k.n_static)];
+        bc = k.dyn_bc + ((long)row * k.n_dyn + (l - k.n_static)) * 3;
+      }
+      const float *vb = k.verts + (long)b * k.V * 3;
+      const float *p0 = vb + (long)k.faces[f * 3 + 0] * 3;
+      const float *p1 = vb + (long)k.faces[f * 3 + 1] * 3;
+      const float *p2 = vb + (long)k.faces[f * 3 + 2] * 3;
+      x = (p0[0] * bc[0] + p1[0] * bc[1]) + p2[0] * bc[2];
+      y = (p0[1] * bc[0] + p1[1] * bc[1]) + p2[1] * bc[2];
+      z = (p0[2] * bc[0] + p1[2] * bc[1]) + p2[2] * bc[2];
+    }
+    float *o = k.joints + ((long)b * k.n_out + i) * 3;
+    o[0] = x; o[1] = y; o[2] = z;
+    if (k.proj) {
+      k.proj[((long)b * k.n_out + i) * 2 + 0] = s * (x + tx);
+      k.proj[((long)b * k.n_out + i) * 2 + 1] = s * (y + ty);
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// stand-alone pose decoders (pose_utils.py:138-153 / rotation_utils.py:5-37) and camera
+// ------------------------------------------------------------------------------------------
+__global__ void pose_decode_kernel(const float *__restrict__ x, int type, float *__restrict__ out,
+                                   long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r[9];
+  if (type == SHAPY_POSE_CONT6D) {
+    const float *p = x + i * 6;
+    const float a1x = p[0], a2x = p[1], a1y = p[2], a2y = p[3], a1z = p[4], a2z = p[5];
+    const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+    const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    const float d = b1x * a2x + b1y * a2y + b1z * a2z;
+    const float cx = a2x - d * b1x, cy = a2y - d * b1y, cz = a2z - d * b1z;
+    const float n2 = fmaxf(sqrtf(cx * cx + cy * cy + cz * cz), 1e-12f);
+    const float b2x = cx / n2, b2y = cy / n2, b2z = cz / n2;
+    r[0] = b1x; r[1] = b2x; r[2] = b1y * b2z - b1z * b2y;
+    r[3] = b1y; r[4] = b2y; r[5] = b1z * b2x - b1x * b2z;
+    r[6] = b1z; r[7] = b2z; r[8] = b1x * b2y - b1y * b2x;
+  } else {
+    const float *p = x + i * 3;
+    const float ex = p[0] + 1e-8f, ey = p[1] + 1e-8f, ez = p[2] + 1e-8f;
+    const float ang = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float rx = p[0] / ang, ry = p[1] / ang, rz = p[2] / ang;
+    const float c = cosf(ang), s = sinf(ang), oc = 1.f - c;
+    const float K[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
+    float KK[9];
+    mat3_mul(K, K, KK);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) r[q] = ((q % 4 == 0) ? 1.f : 0.f) + s * K[q] + oc * KK[q];
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) out[i * 9 + q] = r[q];
+}
+
+__global__ void weak_persp_kernel(const float *__restrict__ pts, const float *__restrict__ scale,
+                                  const float *__restrict__ transl, float *__restrict__ out, int N,
+                                  int scale_first, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long b = i / N;
+  const float s = scale[b], tx = transl[b * 2], ty = transl[b * 2 + 1];
+  const float x = pts[i * 3], y = pts[i * 3 + 1];
+  if (scale_first) {
+    out[i * 2] = s * x + tx;
+    out[i * 2 + 1] = s * y + ty;
+  } else {
+    out[i * 2] = s * (x + tx);
+    out[i * 2 + 1] = s * (y + ty);
+  }
+}
+
+
+// extra joint regressor (body_models.py:738-744): out[b,j,:] = sum_v R[j,v] * vertices[b,v,:]
+__global__ __launch_bounds__(256) void joint_regress_kernel(const float *__restrict__ R,
+                                                            const float *__restrict__ verts,
+                                                            float *__restrict__ out, int V, int Jn) {
+  __shared__ float red[4][3];
+  const int j = blockIdx.x, b = blockIdx.y;
+  const float *r = R + (long)j * V;
+  const float *vb = verts + (long)b * V * 3;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int v = threadIdx.x; v < V; v += 256) {
+    const float w = r[v];
+    sx = fmaf(w, vb[v * 3], sx);
+    sy = fmaf(w, vb[v * 3 + 1], sy);
+    sz = fmaf(w, vb[v * 3 + 2], sz);
+  }
+  sx = wave_reduce_sum(sx); sy = wave_reduce_sum(sy); sz = wave_reduce_sum(sz);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6][0] = sx; red[threadIdx.x >> 6][1] = sy; red[threadIdx.x >> 6][2] = sz;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    out[((long)b * Jn + j) * 3 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+}  // namespace shapy
+
+using namespace shapy;
+
+extern "C" int shapy_regressor_affine_f32(const float *features, const float *Wf, const float *Wp,
+                                          const float *bias, const float *mean_param,
+                                          float *params_out, int B, int F, int P, int num_stages,
+                                          int cond_per_body, void *stream) {
+  if (B <= 0) return SHAPY_OK;
+  if ((F & 3) || P <= 0 || num_stages < 1) return SHAPY_EINVAL;
+  hipLaunchKernelGGL(regressor_affine_kernel, dim3(B), dim3(256), 3 * P * sizeof(float),
+                     (hipStream_t)stream, features, Wf, Wp, bias, mean_param, params_out, B, F, P,
+                     num_stages, cond_per_body ? P : 0);
+  return (int)hipGetLastError();
+}
+
+extern "C" int shapy_smplx_pose_f32(const ShapySmplxModel *m, const float *pose, int pose_type,
+                                    int n_pose, const float *coeffs, float *rot_out,
+                                    float *pose_feat_out, float *A_out, float *joints_out,
+                                    int32_t *dyn_row_out, int B, void *stream) {
+  if (B <= 0) return SHAPY_OK;
+  if (m->J > 64 || n_pose > m->J || m->P != (m->J - 1) * 9) return SHAPY_EINVAL;
+  PoseK k;
+  k.parents = m->parents; k.neck = m->neck_kin_chain; k.Jt = m->J_template; k.Js = m->J_shapedirs;
+  k.pose = pose; k.coeffs = coeffs; k.rot = rot_out; k.pf = pose_feat_out; k.A = A_out;
+  k.joints = joints_out; k.dyn_row = dyn_row_out; k.J = m->J; k.NB = m->NB; k.NBpad = m->NBpad;
+  k.P = m->P; k.Ppad = m->Ppad; k.n_pose = n_pose; k.pose_type = pose_type; k.n_neck = m->n_neck;
+  k.n_dyn_rows = m->n_dyn_rows;
+  hipLaunchKernelGGL(smplx_pose_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, k);
+  return (int)hipGetLastError();
+}
+
+extern "C" int shapy_smplx_skin_f32(const ShapySmplxModel *m, const float *A, const float *v_posed,
+                                    float *vertices_out, int B, void *stream) {
+  if (B <= 0) return SHAPY_OK;
+  if (m->J > 64) return SHAPY_EINVAL;
+  hipLaunchKernelGGL(smplx_skin_kernel, dim3((m->V + 255) / 256, B), dim3(256), 0,
+                     (hipStream_t)stream, m->lbs_weights_t, A, v_posed, vertices_out, m->V, m->J);
+  return (int)hipGetLastError();
+}
+
+extern "C" int shapy_smplx_joints_f32(const ShapySmplxModel *m, const float *posed_joints,
+                                      const float *vertices, const int32_t *dyn_row,
+                                      const float *camera, float *joints_out, float *proj_out,
+                                      float *cam_scale_out, int B, int use_face_contour,
+                                      void *stream) {
+  if (B <= 0) return SHAPY_OK;
+  JointsK k;
+  k.faces = m->faces; k.lmk_idx = m->lmk_faces_idx; k.dyn_idx = m->dyn_lmk_faces_idx;
+  k.dyn_row = dyn_row; k.lmk_bc = m->lmk_bary; k.dyn_bc = m->dyn_lmk_bary; k.posed = posed_joints;
+  k.verts = vertices; k.cam = camera; k.joints = joints_out; k.proj = proj_out;
+  k.scale = cam_scale_out; k.J = m->J; k.V = m->V; k.n_static = m->n_static_lmk;
+  k.n_dyn = use_face_contour ? m->n_dyn_lmk : 0;
+  k.n_out = m->J + k.n_static + k.n_dyn;
+  if (k.n_dyn > 0 && !dyn_row) return SHAPY_EINVAL;
+  hipLaunchKernelGGL(smplx_joints_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, k);
+  return (int)hipGetLastError();
+}
+
+extern "C" int shapy_pose_decode_f32(const float *pose, int pose_type, float *rot_out, int64_t n,
+                                     void *stream) {
+  if (n <= 0) return SHAPY_OK;
+  if (pose_type != SHAPY_POSE_CONT6D && pose_type != SHAPY_POSE_AXIS_ANGLE) return SHAPY_EINVAL;
+  hipLaunchKernelGGL(pose_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, pose, pose_type, rot_out, (long)n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int shapy_weak_persp_project_f32(const float *points, const float *scale,
+                                            const float *translation, float *out, int B, int N,
+                                            int scale_first, void *stream) {
+  const long total = (long)B * N;
+  if (total <= 0) return SHAPY_OK;
+  hipLaunchKernelGGL(weak_persp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, points, scale, translation, out, N, scale_first, total);
+  return (int)hipGetLastError();
+}
+
+extern "C" int shapy_joint_regress_f32(const float *regressor, const float *vertices, float *out,
+                                       int B, int V, int Jn, void *stream) {
+  if (B <= 0 || Jn <= 0) return SHAPY_OK;
+  hipLaunchKernelGGL(joint_regress_kernel, dim3(Jn, B), dim3(256), 0, (hipStream_t)stream, regressor,
+                     vertices, out, V, Jn);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,41 @@
+// Shared declarations of libshapy_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/shapy_hip.h"
+
+namespace shapy {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+enum {
+  SHAPY_TILE_AUTO = 0,
+  SHAPY_TILE_256x48 = 1,
+  SHAPY_TILE_128x96 = 2,
+  SHAPY_TILE_128x128 = 3,
+  SHAPY_TILE_256x64 = 4,
+  SHAPY_TILE_64x48 = 5,
+  SHAPY_TILE_64x96 = 6,
+  SHAPY_TILE_64x128 = 7,
+  SHAPY_TILE_64x64 = 8,
+};
+
+int conv2d_f32(const ShapyConv &d, hipStream_t s);
+int conv_tile_auto(int M, int Cout);
+
+inline int hip_rc(hipError_t e) { return (int)e; }
+
+#define SHAPY_HIP_TRY(expr)                   \
+  do {                                        \
+    hipError_t _e = (expr);                   \
+    if (_e != hipSuccess) return (int)_e;     \
+  } while (0)
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace shapy

@@ -1,0 +1,178 @@
+// HRNet op-list executor + the two non-GEMM kernels of the backbone (stem conv, spatial mean).
+// Reference: regressor/human_shape/models/backbone/hrnet.py:426-498.
+#include <mutex>
+
+#include "common.h"
+
+namespace shapy {
+
+// ---- stem: conv3x3 s2 p1, 3 -> 64 channels, NCHW input -> NHWC output, folded BN + ReLU ----
+// (hrnet.py:427-429).  K = 27 is too small for the matrix cores; 0.5 % of the network's MACs.
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float *__restrict__ in,
+                                                        const float *__restrict__ wgt,
+                                                        const float *__restrict__ bias,
+                                                        float *__restrict__ out, int B, int H, int W,
+                                                        int Ho, int Wo, int out_ld) {
+  __shared__ float w[27 * 64];   // w[k][n], k = (kh*3+kw)*3 + c
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+    const int n = i & 63, k = i >> 6;
+    w[i] = wgt[n * 27 + k];
+  }
+  __syncthreads();
+  const int g = threadIdx.x & 7;
+  const long pix = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const long npix = (long)B * Ho * Wo;
+  if (pix >= npix) return;
+  const int wo = (int)(pix % Wo);
+  const long tq = pix / Wo;
+  const int ho = (int)(tq % Ho);
+  const int b = (int)(tq / Ho);
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const float *inb = in + (long)b * 3 * H * W;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hi = ho * 2 - 1 + kh;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wi = wo * 2 - 1 + kw;
+      const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float x = ok ? inb[((long)c * H + hi) * W + wi] : 0.f;
+        const float *wk = w + ((kh * 3 + kw) * 3 + c) * 64 + g * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(x, wk[i], acc[i]);
+      }
+    }
+  }
+  float *o = out + pix * out_ld + g * 8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = fmaxf(acc[i] + bias[g * 8 + i], 0.f);
+}
+
+// ---- spatial mean over H*W (hrnet.py:484) ----
+__global__ void mean_pool_kernel(const float *__restrict__ in, float *__restrict__ out, int HW,
+                                 int C, int in_ld, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const long b = i / C;
+  const float *p = in + b * HW * in_ld + c;
+  float s = 0.f;
+  for (int k = 0; k < HW; ++k) s += p[(long)k * in_ld];
+  out[i] = s / (float)HW;
+}
+
+// ---- side streams for the independent branches of a HighResolutionModule ----
+struct Lanes {
+  hipStream_t s[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork = nullptr;
+  hipEvent_t join[3] = {nullptr, nullptr, nullptr};
+  bool ready = false;
+};
+static Lanes g_lanes[16];
+static std::mutex g_lanes_mu;
+
+static int get_lanes(Lanes **out) {
+  int dev = 0;
+  SHAPY_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return SHAPY_EINVAL;
+  std::lock_guard<std::mutex> lk(g_lanes_mu);
+  Lanes &L = g_lanes[dev];
+  if (!L.ready) {
+    for (int i = 0; i < 3; ++i) {
+      SHAPY_HIP_TRY(hipStreamCreateWithFlags(&L.s[i], hipStreamNonBlocking));
+      SHAPY_HIP_TRY(hipEventCreateWithFlags(&L.join[i], hipEventDisableTiming));
+    }
+    SHAPY_HIP_TRY(hipEventCreateWithFlags(&L.fork, hipEventDisableTiming));
+    L.ready = true;
+  }
+  *out = &L;
+  return SHAPY_OK;
+}
+
+int hrnet_run_f32(const ShapyOp *ops, int n_ops, const float *weights, const float *input,
+                  float *ws, int64_t ws_per_img, float *features_out, int B, int H, int W,
+                  int multi_stream, hipStream_t main) {
+  Lanes *L = nullptr;
+  if (multi_stream) {
+    int rc = get_lanes(&L);
+    if (rc) return rc;
+  }
+  bool forked[3] = {false, false, false}, dirty[3] = {false, false, false};
+  auto join_all = [&]() -> int {
+    for (int i = 0; i < 3; ++i)
+      if (dirty[i]) {
+        SHAPY_HIP_TRY(hipEventRecord(L->join[i], L->s[i]));
+        SHAPY_HIP_TRY(hipStreamWaitEvent(main, L->join[i], 0));
+        dirty[i] = false;
+      }
+    return SHAPY_OK;
+  };
+  bool fork_recorded = false;
+  for (int idx = 0; idx < n_ops; ++idx) {
+    const ShapyOp &o = ops[idx];
+    hipStream_t s = main;
+    if (multi_stream) {
+      if (o.barrier_before) {
+        int rc = join_all();
+        if (rc) return rc;
+        forked[0] = forked[1] = forked[2] = false;
+        fork_recorded = false;
+      }
+      if (o.lane > 0 && o.lane <= 3) {
+        const int li = o.lane - 1;
+        if (!forked[li]) {
+          if (!fork_recorded) {
+            SHAPY_HIP_TRY(hipEventRecord(L->fork, main));
+            fork_recorded = true;
+          }
+          SHAPY_HIP_TRY(hipStreamWaitEvent(L->s[li], L->fork, 0));
+          forked[li] = true;
+        }
+        s = L->s[li];
+        dirty[li] = true;
+      } else {
+        // lane-0 work enqueued after the fork point must not delay later forks
+      }
+    }
+    auto buf = [&](int64_t off) -> float * { return off < 0 ? nullptr : ws + off * (int64_t)B; };
+    if (o.type == SHAPY_OP_CONV) {
+      ShapyConv d;
+      d.in = buf(o.in_off);
+      d.wgt = weights + o.wgt_off;
+      d.bias = o.bias_off >= 0 ? weights + o.bias_off : nullptr;
+      d.res = buf(o.res_off);
+      d.out = buf(o.out_off);
+      d.B = B; d.Hi = o.Hi; d.Wi = o.Wi; d.Cin = o.Cin; d.in_ld = o.in_ld;
+      d.Ho = o.Ho; d.Wo = o.Wo; d.Cout = o.Cout; d.ksize = o.ksize; d.stride = o.stride;
+      d.pad = o.pad; d.out_ld = o.out_ld; d.out_coff = o.out_coff; d.res_ld = o.res_ld;
+      d.res_coff = o.res_coff; d.relu = o.relu; d.ups = o.ups; d.tile = o.tile;
+      int rc = conv2d_f32(d, s);
+      if (rc) return rc;
+    } else if (o.type == SHAPY_OP_STEM) {
+      if (o.Cin != 3 || o.Cout != 64 || o.ksize != 3 || o.stride != 2) return SHAPY_EINVAL;
+      const long npix = (long)B * o.Ho * o.Wo;
+      hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((npix + 31) / 32)), dim3(256), 0, s,
+                         input, weights + o.wgt_off, weights + o.bias_off, buf(o.out_off), B, H, W,
+                         o.Ho, o.Wo, o.out_ld);
+      SHAPY_HIP_TRY(hipGetLastError());
+    } else if (o.type == SHAPY_OP_MEANPOOL) {
+      const long total = (long)B * o.Cin;
+      hipLaunchKernelGGL(mean_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                         buf(o.in_off), features_out, o.Hi * o.Wi, o.Cin, o.in_ld, total);
+      SHAPY_HIP_TRY(hipGetLastError());
+    } else {
+      return SHAPY_EINVAL;
+    }
+  }
+  if (multi_stream) {
+    int rc = join_all();
+    if (rc) return rc;
+  }
+  return SHAPY_OK;
+}
+
+}  // namespace shapy

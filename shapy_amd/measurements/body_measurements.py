@@ -1,0 +1,107 @@
+"""Virtual body measurements on gfx950.
+
+Drop-in for ``BodyMeasurements`` (mesh-mesh-intersection/body_measurements/
+body_measurements.py:17-246): same config keys (``meas_definition_path``,
+``meas_vertices_path``, ``max_collisions``), same ``forward(triangles [B,F,3,3])`` signature
+and the same ``{'measurements': {name: {'tensor': [B]}}}`` result.
+
+Two execution paths, both entirely on the GPU:
+  * ``forward(triangles)`` -- the reference's signature.  Runs the intersection *operator*
+    (``MeshMeshIntersection``) per plane and then the fused hull kernel... the operator
+    result is consumed exactly like body_measurements.py:141-179 does.
+  * ``forward_vertices(v_shaped, faces)`` -- what the regressor calls: one fused launch pair
+    (csrc/measure.hip) straight from ``v_shaped`` and the int32 face table; the
+    ``[B,F,3,3]`` triangle tensor (752 KB per body) is never materialised.
+"""
+import ctypes
+import os.path as osp
+
+import numpy as np
+import torch
+import torch.nn as nn
+import yaml
+
+from .. import _lib
+from .mesh_mesh_intersection import MeshMeshIntersection
+
+
+class BodyMeasurements(nn.Module):
+    DENSITY = 985       # kg / m^3 (body_measurements.py:20)
+    NAMES = ('mass', 'height', 'chest', 'waist', 'hips')
+
+    def __init__(self, cfg, **kwargs):
+        super().__init__()
+        expand = lambda p: osp.expanduser(osp.expandvars(p))
+        with open(expand(cfg.get('meas_definition_path', '')), 'r') as f:
+            defs = yaml.safe_load(f)
+        with open(expand(cfg.get('meas_vertices_path', '')), 'r') as f:
+            verts = yaml.safe_load(f)
+        head_top, left_heel = verts['HeadTop'], verts['HeelLeft']
+        self.left_heel_face_idx = left_heel['face_idx']
+        self.register_buffer('left_heel_bc', torch.tensor(left_heel['bc'], dtype=torch.float32))
+        self.register_buffer('head_top_bc', torch.tensor(head_top['bc'], dtype=torch.float32))
+        self.head_top_face_idx = head_top['face_idx']
+        chest = verts[defs['CW_p'][0]]
+        self.chest_face_index = chest['face_idx']
+        self.register_buffer('chest_bcs', torch.tensor(chest['bc'], dtype=torch.float32))
+        belly = verts[defs['BW_p'][0]]
+        self.belly_face_index = belly['face_idx']
+        self.register_buffer('belly_bcs', torch.tensor(belly['bc'], dtype=torch.float32))
+        hips = verts[defs['IW_p'][0]]
+        self.hips_face_index = hips['face_idx']
+        self.register_buffer('hips_bcs', torch.tensor(hips['bc'], dtype=torch.float32))
+        self.max_collisions = cfg.get('max_collisions', 256)
+        self.isect_module = MeshMeshIntersection(max_collisions=self.max_collisions)
+        # host copies for the fused kernel's by-value landmark table
+        self._lm_face = (ctypes.c_int32 * 5)(
+            self.head_top_face_idx, self.left_heel_face_idx, self.chest_face_index,
+            self.belly_face_index, self.hips_face_index)
+        bcs = [head_top['bc'], left_heel['bc'], chest['bc'], belly['bc'], hips['bc']]
+        self._lm_bc = (ctypes.c_float * 15)(*[np.float32(x) for bc in bcs for x in bc])
+        self.last_overflow = None
+
+    def extra_repr(self):
+        return f'Human Body Density: {self.DENSITY}'
+
+    def forward_vertices(self, v_shaped, faces_i32):
+        """v_shaped [B,V,3] f32, faces [F,3] int32 -> [B,5] (mass, height, chest, waist, hips)."""
+        _lib.require_cuda(v_shaped, 'v_shaped')
+        lib = _lib.load()
+        v = v_shaped.contiguous().float()
+        B, V = v.shape[:2]
+        F = faces_i32.shape[0]
+        nbytes = lib.shapy_body_measure_workspace_bytes(B, F, self.max_collisions)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=v.device)
+        out = torch.empty(B, 5, dtype=torch.float32, device=v.device)
+        overflow = torch.zeros(1, dtype=torch.int32, device=v.device)
+        _lib.check(lib.shapy_body_measure_f32(
+            _lib.ptr(v), _lib.ptr(faces_i32), B, V, F, self._lm_face, self._lm_bc,
+            self.max_collisions, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.ptr(overflow),
+            _lib.current_stream()), 'shapy_body_measure_f32')
+        self.last_overflow = overflow
+        return out
+
+    def _result(self, out, flags):
+        meas = {}
+        for i, name in enumerate(self.NAMES):
+            if flags[i]:
+                meas[name] = {'tensor': out[:, i]}
+        return {'measurements': meas}
+
+    def measure_vertices(self, v_shaped, faces_i32, compute_mass=True, compute_height=True,
+                         compute_chest=True, compute_waist=True, compute_hips=True):
+        out = self.forward_vertices(v_shaped, faces_i32)
+        return self._result(out, (compute_mass, compute_height, compute_chest, compute_waist,
+                                  compute_hips))
+
+    def forward(self, triangles, compute_mass=True, compute_height=True, compute_chest=True,
+                compute_waist=True, compute_hips=True, **kwargs):
+        """triangles [B,F,3,3] (the reference's signature, body_measurements.py:217-246).
+        The triangle soup is re-indexed as a mesh with 3F vertices and fed to the fused path;
+        results are identical because every kernel only ever looks at whole triangles."""
+        _lib.require_cuda(triangles, 'triangles')
+        B, F = triangles.shape[:2]
+        v = triangles.reshape(B, F * 3, 3)
+        faces = torch.arange(F * 3, dtype=torch.int32, device=triangles.device).view(F, 3)
+        return self.measure_vertices(v, faces, compute_mass, compute_height, compute_chest,
+                                     compute_waist, compute_hips)

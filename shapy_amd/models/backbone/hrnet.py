@@ -1,0 +1,633 @@
+"""HRNet-W48 (SHAPY variant) on hand-written gfx950 kernels.
+
+Drop-in for ``regressor/human_shape/models/backbone/hrnet.py``: same constructor config
+(``cfg.stage1..4``, ``pretrained_layers``, ``use_old_impl``), same ``state_dict`` key layout
+(``conv1.weight``, ``layer1.0.conv1.weight``, ``stage3.2.fuse_layers.1.0.0.0.weight``, ...) so
+the reference's checkpoints load with ``load_state_dict``, same ``forward`` contract
+(``[B,3,H,W]`` NCHW f32 -> ``{'concat': [B,2048]}``), same ``get_output_dim`` /
+``load_weights``.
+
+The ``torch.nn`` modules below are *parameter containers only* -- none of their ``forward``
+methods is ever called.  ``forward`` compiles the tree once into
+
+  * one weight blob: BatchNorm folded into conv weight/bias in float64, OIHW -> OHWI
+    (K-contiguous rows for the MFMA B operand), and
+  * a flat op list (``ShapyOp[]``) over a liveness-packed NHWC activation workspace,
+
+and hands both to ``shapy_hrnet_run_f32`` (csrc/hrnet_ops.hip), which launches the
+implicit-GEMM MFMA kernel (csrc/conv_igemm.hip) per conv with the residual add, ReLU, the
+nearest-upsample + add of the fuse layers and the channel concat fused into its epilogue.
+The independent branches of a HighResolutionModule are issued on separate HIP streams.
+"""
+import ctypes
+import os.path as osp
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _lib
+
+BN_MOMENTUM = 0.1
+
+
+# ------------------------------------------------------------------------------------------
+# parameter containers (names follow torchvision 0.8.2 BasicBlock / Bottleneck, which the
+# reference instantiates at hrnet.py:13,196-199,369-370)
+# ------------------------------------------------------------------------------------------
+class _Container(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError('parameter container: executed by the HIP engine, not by torch')
+
+
+class BasicBlock(_Container):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class Bottleneck(_Container):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+
+blocks_dict = {'BASIC': BasicBlock, 'BOTTLENECK': Bottleneck}
+
+
+class HighResolutionModule(_Container):
+    """Parameter layout of hrnet.py:29-170."""
+
+    def __init__(self, num_branches, block, num_blocks, num_inchannels, num_channels,
+                 fuse_method, multi_scale_output=True):
+        super().__init__()
+        if not (num_branches == len(num_blocks) == len(num_channels) == len(num_inchannels)):
+            raise ValueError('NUM_BRANCHES <> NUM_BLOCKS / NUM_CHANNELS / NUM_INCHANNELS')
+        self.num_inchannels = list(num_inchannels)
+        self.fuse_method = fuse_method
+        self.num_branches = num_branches
+        self.multi_scale_output = multi_scale_output
+        branches = []
+        for i in range(num_branches):
+            downsample = None
+            if self.num_inchannels[i] != num_channels[i] * block.expansion:
+                downsample = nn.Sequential(
+                    nn.Conv2d(self.num_inchannels[i], num_channels[i] * block.expansion, 1, 1,
+                              bias=False),
+                    nn.BatchNorm2d(num_channels[i] * block.expansion, momentum=BN_MOMENTUM))
+            layers = [block(self.num_inchannels[i], num_channels[i], 1, downsample)]
+            self.num_inchannels[i] = num_channels[i] * block.expansion
+            for _ in range(1, num_blocks[i]):
+                layers.append(block(self.num_inchannels[i], num_channels[i]))
+            branches.append(nn.Sequential(*layers))
+        self.branches = nn.ModuleList(branches)
+        self.fuse_layers = self._make_fuse_layers()
+
+    def _make_fuse_layers(self):
+        if self.num_branches == 1:
+            return None
+        nb, ch = self.num_branches, self.num_inchannels
+        fuse_layers = []
+        for i in range(nb if self.multi_scale_output else 1):
+            fuse_layer = []
+            for j in range(nb):
+                if j > i:
+                    fuse_layer.append(nn.Sequential(
+                        nn.Conv2d(ch[j], ch[i], 1, 1, 0, bias=False),
+                        nn.BatchNorm2d(ch[i]),
+                        nn.Upsample(scale_factor=2 ** (j - i), mode='nearest')))
+                elif j == i:
+                    fuse_layer.append(None)
+                else:
+                    convs = []
+                    for k in range(i - j):
+                        if k == i - j - 1:
+                            convs.append(nn.Sequential(
+                                nn.Conv2d(ch[j], ch[i], 3, 2, 1, bias=False),
+                                nn.BatchNorm2d(ch[i])))
+                        else:
+                            convs.append(nn.Sequential(
+                                nn.Conv2d(ch[j], ch[j], 3, 2, 1, bias=False),
+                                nn.BatchNorm2d(ch[j]), nn.ReLU(True)))
+                    fuse_layer.append(nn.Sequential(*convs))
+            fuse_layers.append(nn.ModuleList(fuse_layer))
+        return nn.ModuleList(fuse_layers)
+
+    def get_num_inchannels(self):
+        return self.num_inchannels
+
+
+# ------------------------------------------------------------------------------------------
+# plan builder
+# ------------------------------------------------------------------------------------------
+class _Buf:
+    __slots__ = ('H', 'W', 'C', 'size', 'uses', 'off')
+
+    def __init__(self, H, W, C):
+        self.H, self.W, self.C = H, W, C
+        self.size = H * W * C
+        self.uses = []        # (epoch, lane, op index)
+        self.off = None
+
+
+def _pack(items):
+    """First-fit offset assignment.  items: [(start, end, size, obj)], closed intervals;
+    two items may share memory iff their intervals are disjoint.  Sets obj.off (4-float
+    aligned) and returns the arena size."""
+    live, total = [], 0
+    for start, end, size, obj in sorted(items, key=lambda it: (it[0], -it[2])):
+        live = [x for x in live if x[2] >= start]
+        live.sort()
+        off = 0
+        for (o, s, _) in live:
+            if off + size <= o:
+                break
+            off = max(off, o + s)
+        off = (off + 3) // 4 * 4
+        obj.off = off
+        live.append((off, size, end))
+        total = max(total, off + size)
+    return (total + 3) // 4 * 4
+
+
+class _Plan:
+    """Flat op list + weight packing for one input resolution."""
+
+    def __init__(self):
+        self.ops = []          # dicts
+        self.bufs = []
+        self.wchunks = []      # float32 numpy arrays
+        self.woff = 0
+        self.epoch = 0
+        self._pending_barrier = False
+
+    def buf(self, H, W, C):
+        b = _Buf(H, W, C)
+        self.bufs.append(b)
+        return b
+
+    def barrier(self):
+        self._pending_barrier = True
+
+    def add_weights(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        off = self.woff
+        pad = (-arr.size) % 4
+        self.wchunks.append(arr)
+        if pad:
+            self.wchunks.append(np.zeros(pad, np.float32))
+        self.woff += arr.size + pad
+        return off
+
+    def op(self, **kw):
+        if self._pending_barrier:
+            self.epoch += 1
+            kw['barrier_before'] = 1
+            self._pending_barrier = False
+        else:
+            kw.setdefault('barrier_before', 0)
+        for key in ('inb', 'outb', 'resb'):
+            b = kw.get(key)
+            if b is not None:
+                b.uses.append((self.epoch, kw['lane'], len(self.ops)))
+        self.ops.append(kw)
+
+    def allocate(self):
+        """Liveness packing of the activation workspace (floats per image).
+
+        Ops of different lanes inside one epoch (= between two barriers) run concurrently on
+        different HIP streams, so a buffer touched from several lanes or epochs is live for
+        its whole [first epoch, last epoch] interval.  Buffers confined to ONE (epoch, lane)
+        -- the temporaries of a residual-block chain -- are packed by op order inside a
+        per-(epoch, lane) arena, which is itself live only during that epoch."""
+        used = [b for b in self.bufs if b.uses]
+        groups, global_items = {}, []
+        for b in used:
+            keys = {(e, l) for e, l, _ in b.uses}
+            if len(keys) == 1:
+                groups.setdefault(next(iter(keys)), []).append(b)
+            else:
+                es = [e for e, _, _ in b.uses]
+                global_items.append((min(es), max(es), b.size, b))
+        arenas = []
+        for (e, l), bs in groups.items():
+            arena = _Buf(0, 0, 0)
+            arena.size = _pack([(min(u[2] for u in b.uses), max(u[2] for u in b.uses), b.size, b)
+                                for b in bs])
+            arenas.append((arena, bs))
+            global_items.append((e, e, arena.size, arena))
+        total = _pack(global_items)
+        for arena, bs in arenas:
+            for b in bs:
+                b.off += arena.off
+        return total
+
+
+def _fold(conv, bn):
+    """conv (+bias) followed by eval-mode BN -> (weight OHWI, bias) in float64 -> float32.
+    BN: y = (x - mean) / sqrt(var + eps) * gamma + beta  (eps 1e-5)."""
+    w = conv.weight.detach().double().cpu()
+    cout = w.shape[0]
+    b = conv.bias.detach().double().cpu() if conv.bias is not None else torch.zeros(cout, dtype=torch.float64)
+    if bn is not None:
+        scale = bn.weight.detach().double().cpu() / torch.sqrt(
+            bn.running_var.detach().double().cpu() + bn.eps)
+        w = w * scale.view(-1, 1, 1, 1)
+        b = (b - bn.running_mean.detach().double().cpu()) * scale + bn.bias.detach().double().cpu()
+    w = w.permute(0, 2, 3, 1).contiguous()          # OIHW -> OHWI
+    return w.float().numpy(), b.float().numpy()
+
+
+class HighResolutionNet(nn.Module):
+
+    def __init__(self, cfg, **kwargs):
+        super().__init__()
+        self.inplanes = 64
+        self.use_old_impl = bool(cfg.get('use_old_impl', False))
+        if self.use_old_impl:
+            raise NotImplementedError('use_old_impl=True is not used by any SHAPY config')
+        self.conv1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(64, momentum=BN_MOMENTUM)
+
+        self.stage1_cfg = cfg.get('stage1', {})
+        num_channels = self.stage1_cfg['num_channels'][0]
+        block = blocks_dict[self.stage1_cfg['block']]
+        num_blocks = self.stage1_cfg['num_blocks'][0]
+        self.layer1 = self._make_layer(block, num_channels, num_blocks)
+        stage1_out_channel = block.expansion * num_channels
+
+        self.stage2_cfg = cfg.get('stage2', {})
+        block = blocks_dict[self.stage2_cfg.get('block')]
+        num_channels = [c * block.expansion for c in self.stage2_cfg.get('num_channels', (32, 64))]
+        stage2_num_channels = num_channels
+        self.transition1 = self._make_transition_layer([stage1_out_channel], num_channels)
+        self.stage2, pre = self._make_stage(self.stage2_cfg, num_channels)
+
+        self.stage3_cfg = cfg.get('stage3')
+        block = blocks_dict[self.stage3_cfg['block']]
+        num_channels = [c * block.expansion for c in self.stage3_cfg['num_channels']]
+        stage3_num_channels = num_channels
+        self.transition2 = self._make_transition_layer(pre, num_channels)
+        self.stage3, pre = self._make_stage(self.stage3_cfg, num_channels)
+
+        self.stage4_cfg = cfg.get('stage4')
+        block = blocks_dict[self.stage4_cfg['block']]
+        num_channels = [c * block.expansion for c in self.stage4_cfg['num_channels']]
+        self.transition3 = self._make_transition_layer(pre, num_channels)
+        self.stage4, pre = self._make_stage(self.stage4_cfg, num_channels)
+        stage4_num_channels = num_channels
+        self.output_channels_dim = pre
+        self.pretrained_layers = list(cfg['pretrained_layers'])
+
+        in_dims = 4 * 384                       # hrnet.py:279
+        self.subsample_4 = self._make_subsample_layer(stage4_num_channels[0], 3)
+        self.subsample_3 = self._make_subsample_layer(stage2_num_channels[-1], 2)
+        self.subsample_2 = self._make_subsample_layer(stage3_num_channels[-1], 1)
+        self.conv_layers = self._make_conv_layer(in_dims, 5)
+        self.init_weights()
+        self._engine = {}
+        self.multi_stream = True
+        self.tile_overrides = {}
+        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
+
+    # ---- construction helpers (mirror hrnet.py:301-424) ----
+    def _make_transition_layer(self, pre, cur):
+        layers = []
+        for i in range(len(cur)):
+            if i < len(pre):
+                if cur[i] != pre[i]:
+                    layers.append(nn.Sequential(nn.Conv2d(pre[i], cur[i], 3, 1, 1, bias=False),
+                                                nn.BatchNorm2d(cur[i]), nn.ReLU(inplace=True)))
+                else:
+                    layers.append(None)
+            else:
+                convs = []
+                for j in range(i + 1 - len(pre)):
+                    inch = pre[-1]
+                    outch = cur[i] if j == i - len(pre) else inch
+                    convs.append(nn.Sequential(nn.Conv2d(inch, outch, 3, 2, 1, bias=False),
+                                               nn.BatchNorm2d(outch), nn.ReLU(inplace=True)))
+                layers.append(nn.Sequential(*convs))
+        return nn.ModuleList(layers)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion, momentum=BN_MOMENTUM))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def _make_conv_layer(self, in_channels=2048, num_layers=3, num_filters=2048):
+        layers = []
+        for _ in range(num_layers):
+            downsample = nn.Conv2d(in_channels, num_filters, 1, 1, bias=False)
+            layers.append(Bottleneck(in_channels, num_filters // 4, downsample=downsample))
+            in_channels = num_filters
+        return nn.Sequential(*layers)
+
+    def _make_subsample_layer(self, in_channels=96, num_layers=3, stride=2):
+        layers = []
+        for _ in range(num_layers):
+            layers.append(nn.Conv2d(in_channels, 2 * in_channels, 3, stride, 1))
+            in_channels *= 2
+            layers.append(nn.BatchNorm2d(in_channels, momentum=BN_MOMENTUM))
+            layers.append(nn.ReLU(inplace=True))
+        return nn.Sequential(*layers)
+
+    def _make_stage(self, layer_config, num_inchannels, multi_scale_output=True):
+        block = blocks_dict[layer_config['block']]
+        modules = []
+        for i in range(layer_config['num_modules']):
+            reset = not (not multi_scale_output and i == layer_config['num_modules'] - 1)
+            modules.append(HighResolutionModule(
+                layer_config['num_branches'], block, layer_config['num_blocks'],
+                num_inchannels, layer_config['num_channels'], layer_config['fuse_method'],
+                reset))
+            num_inchannels = modules[-1].get_num_inchannels()
+        return nn.Sequential(*modules), num_inchannels
+
+    def get_output_dim(self):
+        base = {f'layer{i + 1}': v for i, v in enumerate(self.output_channels_dim)}
+        out = dict(base)
+        for k in base:
+            out[f'{k}_avg_pooling'] = base[k]
+        out['concat'] = 2048
+        return out
+
+    def init_weights(self):
+        """hrnet.py:500-516."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, std=0.001)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def load_weights(self, pretrained=''):
+        """hrnet.py:518-534."""
+        pretrained = osp.expandvars(pretrained or '')
+        if osp.isfile(pretrained):
+            sd = torch.load(pretrained, map_location=torch.device('cpu'))
+            need = {k: v for k, v in sd.items()
+                    if k.split('.')[0] in self.pretrained_layers or self.pretrained_layers[0] == '*'}
+            self.load_state_dict(need, strict=False)
+        elif pretrained:
+            raise ValueError('{} is not exist!'.format(pretrained))
+
+    # ---- engine ----
+    def invalidate(self):
+        self._engine = {}
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._engine = {}
+        return out
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st['_engine'] = {}
+        return st
+
+    def _build_plan(self, H, W):
+        P = _Plan()
+        ov = self.tile_overrides
+
+        def conv(conv_m, bn, inb, Hi, Wi, outb=None, res=None, relu=False, ups=1, lane=0,
+                 out_ld=None, out_coff=0, res_ld=None, res_coff=0, name=''):
+            ks, st, pad = conv_m.kernel_size[0], conv_m.stride[0], conv_m.padding[0]
+            cin, cout = conv_m.in_channels, conv_m.out_channels
+            Ho, Wo = (Hi + 2 * pad - ks) // st + 1, (Wi + 2 * pad - ks) // st + 1
+            w, b = _fold(conv_m, bn)
+            if outb is None:
+                outb = P.buf(Ho * ups, Wo * ups, cout)
+            P.op(type=_lib.OP_CONV, lane=lane, inb=inb, outb=outb, resb=res, Hi=Hi, Wi=Wi, Cin=cin,
+                 in_ld=inb.C, Ho=Ho, Wo=Wo, Cout=cout, ksize=ks, stride=st, pad=pad,
+                 out_ld=out_ld or outb.C, out_coff=out_coff,
+                 res_ld=(res_ld or (res.C if res is not None else 0)), res_coff=res_coff,
+                 relu=int(relu), ups=ups, tile=_lib.TILES[ov.get(name, 'auto')],
+                 wgt_off=P.add_weights(w), bias_off=P.add_weights(b))
+            return outb, Ho, Wo
+
+        # stem (hrnet.py:427-432)
+        H1, W1 = H // 2, W // 2
+        w, b = _fold(self.conv1, self.bn1)
+        s1 = P.buf(H1, W1, 64)
+        P.op(type=_lib.OP_STEM, lane=0, inb=None, outb=s1, resb=None, Hi=H, Wi=W, Cin=3, in_ld=0,
+             Ho=H1, Wo=W1, Cout=64, ksize=3, stride=2, pad=1, out_ld=64, out_coff=0, res_ld=0,
+             res_coff=0, relu=1, ups=1, tile=0, wgt_off=P.add_weights(w.reshape(64, 27)),
+             bias_off=P.add_weights(b))
+        x, Hc, Wc = conv(self.conv2, self.bn2, s1, H1, W1, relu=True, name='conv2')
+
+        def bottleneck(m, x, Hc, Wc, lane=0, side_lane=None, name=''):
+            idt = x
+            if m.downsample is not None:
+                if isinstance(m.downsample, nn.Conv2d):       # conv_layers: bare 1x1 conv
+                    if side_lane is not None:
+                        P.barrier()
+                    idt, _, _ = conv(m.downsample, None, x, Hc, Wc,
+                                     lane=side_lane if side_lane is not None else lane,
+                                     name=name + '.downsample')
+                else:
+                    idt, _, _ = conv(m.downsample[0], m.downsample[1], x, Hc, Wc, lane=lane,
+                                     name=name + '.downsample')
+            t, _, _ = conv(m.conv1, m.bn1, x, Hc, Wc, relu=True, lane=lane, name=name + '.conv1')
+            t, _, _ = conv(m.conv2, m.bn2, t, Hc, Wc, relu=True, lane=lane, name=name + '.conv2')
+            if side_lane is not None:
+                P.barrier()
+            o, _, _ = conv(m.conv3, m.bn3, t, Hc, Wc, res=idt, relu=True, lane=lane,
+                           name=name + '.conv3')
+            return o
+
+        for bi, m in enumerate(self.layer1):
+            x = bottleneck(m, x, Hc, Wc, name=f'layer1.{bi}')
+
+        def seq_conv_bn_relu(seq, x, Hc, Wc, lane, name):
+            # Sequential(conv, bn, relu) or Sequential(Sequential(conv,bn,relu), ...)
+            if isinstance(seq[0], nn.Conv2d):
+                return conv(seq[0], seq[1], x, Hc, Wc, relu=True, lane=lane, name=name)
+            for q, s in enumerate(seq):
+                x, Hc, Wc = conv(s[0], s[1], x, Hc, Wc, relu=True, lane=lane, name=f'{name}.{q}')
+            return x, Hc, Wc
+
+        def module(m, xs, last_out=None, name=''):
+            """xs: list of (buf, H, W).  HighResolutionModule.forward (hrnet.py:175-193)."""
+            nb = m.num_branches
+            ys = []
+            for i in range(nb):
+                x, Hc, Wc = xs[i]
+                for bi, blk in enumerate(m.branches[i]):
+                    t, _, _ = conv(blk.conv1, blk.bn1, x, Hc, Wc, relu=True, lane=i,
+                                   name=f'{name}.branches.{i}.{bi}.conv1')
+                    x, _, _ = conv(blk.conv2, blk.bn2, t, Hc, Wc, res=x, relu=True, lane=i,
+                                   name=f'{name}.branches.{i}.{bi}.conv2')
+                ys.append((x, Hc, Wc))
+            P.barrier()
+            outs = []
+            for i in range(len(m.fuse_layers)):
+                xi, Hi_, Wi_ = ys[i]
+                terms = [j for j in range(nb) if j != i]
+                use_last = last_out is not None and i == nb - 1
+                outb = last_out[0] if use_last else P.buf(Hi_, Wi_, xi.C)
+                o_ld = last_out[1] if use_last else xi.C
+                o_co = last_out[2] if use_last else 0
+                for ti, j in enumerate(terms):
+                    first, last = ti == 0, ti == len(terms) - 1
+                    res = xi if first else outb
+                    r_ld = xi.C if first else o_ld
+                    r_co = 0 if first else o_co
+                    xj, Hj, Wj = ys[j]
+                    fl = m.fuse_layers[i][j]
+                    nm = f'{name}.fuse_layers.{i}.{j}'
+                    if j > i:
+                        conv(fl[0], fl[1], xj, Hj, Wj, outb=outb, res=res, relu=last,
+                             ups=2 ** (j - i), lane=i, out_ld=o_ld, out_coff=o_co, res_ld=r_ld,
+                             res_coff=r_co, name=nm)
+                    else:
+                        t, Ht, Wt = xj, Hj, Wj
+                        for k in range(i - j):
+                            if k == i - j - 1:
+                                conv(fl[k][0], fl[k][1], t, Ht, Wt, outb=outb, res=res, relu=last,
+                                     lane=i, out_ld=o_ld, out_coff=o_co, res_ld=r_ld,
+                                     res_coff=r_co, name=f'{nm}.{k}')
+                            else:
+                                t, Ht, Wt = conv(fl[k][0], fl[k][1], t, Ht, Wt, relu=True, lane=i,
+                                                 name=f'{nm}.{k}')
+                outs.append((outb, Hi_, Wi_))
+            return outs
+
+        # transition1 (hrnet.py:435-440)
+        P.barrier()
+        xs = []
+        for i, tr in enumerate(self.transition1):
+            xs.append((x, Hc, Wc) if tr is None else
+                      seq_conv_bn_relu(tr, x, Hc, Wc, i, f'transition1.{i}'))
+        ys = xs
+        stages = [(self.stage2, self.transition2), (self.stage3, self.transition3),
+                  (self.stage4, None)]
+        cat = None
+        for si, (stage, trans) in enumerate(stages):
+            for mi, m in enumerate(stage):
+                last = None
+                if trans is None and mi == len(stage) - 1:
+                    # the last module writes branch 3 straight into the concat buffer (x1)
+                    Hl, Wl = ys[-1][1], ys[-1][2]
+                    cat = P.buf(Hl, Wl, 4 * 384)
+                    last = (cat, 4 * 384, 3 * 384)
+                ys = module(m, ys, last_out=last, name=f'stage{si + 2}.{mi}')
+            if trans is not None:
+                P.barrier()
+                nxt = []
+                for i, tr in enumerate(trans):
+                    if tr is None:
+                        nxt.append(ys[i])
+                    else:
+                        src = ys[i] if i < len(ys) else ys[-1]
+                        nxt.append(seq_conv_bn_relu(tr, src[0], src[1], src[2], i,
+                                                    f'transition{si + 2}.{i}'))
+                ys = nxt
+
+        # head (hrnet.py:477-486): cat[x4, x3, x2, x1] -> 5 bottlenecks -> spatial mean
+        P.barrier()
+
+        def subsample(seq, src, lane, coff, name):
+            x, Hc, Wc = src
+            n = len(seq) // 3
+            for q in range(n):
+                if q == n - 1:
+                    conv(seq[3 * q], seq[3 * q + 1], x, Hc, Wc, outb=cat, relu=True, lane=lane,
+                         out_ld=cat.C, out_coff=coff, name=f'{name}.{3 * q}')
+                else:
+                    x, Hc, Wc = conv(seq[3 * q], seq[3 * q + 1], x, Hc, Wc, relu=True, lane=lane,
+                                     name=f'{name}.{3 * q}')
+        subsample(self.subsample_4, ys[0], 0, 0, 'subsample_4')
+        subsample(self.subsample_3, ys[1], 1, 384, 'subsample_3')
+        subsample(self.subsample_2, ys[2], 2, 768, 'subsample_2')
+        P.barrier()
+        Hc, Wc = ys[3][1], ys[3][2]
+        x = cat
+        for bi, m in enumerate(self.conv_layers):
+            x = bottleneck(m, x, Hc, Wc, lane=0, side_lane=1, name=f'conv_layers.{bi}')
+            P.barrier()
+        P.op(type=_lib.OP_MEANPOOL, lane=0, inb=x, outb=None, resb=None, Hi=Hc, Wi=Wc, Cin=x.C,
+             in_ld=x.C, Ho=1, Wo=1, Cout=x.C, ksize=1, stride=1, pad=0, out_ld=x.C, out_coff=0,
+             res_ld=0, res_coff=0, relu=0, ups=1, tile=0, wgt_off=-1, bias_off=-1)
+        return P
+
+    def _compile(self, H, W, device):
+        key = (H, W, str(device))
+        eng = self._engine.get(key)
+        if eng is not None:
+            return eng
+        P = self._build_plan(H, W)
+        ws_per_img = P.allocate()
+        n = len(P.ops)
+        arr = (_lib.ShapyOp * n)()
+        for i, o in enumerate(P.ops):
+            a = arr[i]
+            for f in ('type', 'lane', 'barrier_before', 'Hi', 'Wi', 'Cin', 'in_ld', 'Ho', 'Wo',
+                      'Cout', 'ksize', 'stride', 'pad', 'out_ld', 'out_coff', 'res_ld', 'res_coff',
+                      'relu', 'ups', 'tile', 'wgt_off', 'bias_off'):
+                setattr(a, f, int(o[f]))
+            a.in_off = -2 if o['type'] == _lib.OP_STEM else o['inb'].off
+            a.out_off = -1 if o['outb'] is None else o['outb'].off
+            a.res_off = -1 if o['resb'] is None else o['resb'].off
+        weights = torch.from_numpy(np.concatenate(P.wchunks)).to(device)
+        eng = dict(ops=arr, n_ops=n, weights=weights, ws_per_img=ws_per_img, plan=P, ws=None,
+                   feat_dim=P.ops[-1]['Cin'])
+        self._engine[key] = eng
+        return eng
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f'expected [B,3,H,W], got {tuple(x.shape)}')
+        _lib.require_cuda(x, 'images')
+        lib = _lib.load()
+        B, _, H, W = x.shape
+        if H % 32 or W % 32:
+            raise ValueError('HRNet input height/width must be multiples of 32')
+        x = x.contiguous().float()
+        eng = self._compile(H, W, x.device)
+        need = eng['ws_per_img'] * B
+        if eng['ws'] is None or eng['ws'].numel() < need:
+            eng['ws'] = torch.empty(need, dtype=torch.float32, device=x.device)
+        feat = torch.empty(B, eng['feat_dim'], dtype=torch.float32, device=x.device)
+        rc = lib.shapy_hrnet_run_f32(eng['ops'], eng['n_ops'], _lib.ptr(eng['weights']),
+                                     _lib.ptr(x), _lib.ptr(eng['ws']), eng['ws_per_img'],
+                                     _lib.ptr(feat), B, H, W, int(self.multi_stream),
+                                     _lib.current_stream())
+        _lib.check(rc, 'shapy_hrnet_run_f32')
+        return {'concat': feat}
+
+
+def build(cfg, pretrained=True, **kwargs):
+    """hrnet.py:18-26."""
+    hr_net_cfg = cfg.get('hrnet')
+    model = HighResolutionNet(hr_net_cfg, **kwargs)
+    if pretrained:
+        model.load_weights(hr_net_cfg.get('pretrained_path'))
+    return model

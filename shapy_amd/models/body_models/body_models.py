@@ -1,0 +1,344 @@
+"""SMPL-X layer on gfx950 kernels.
+
+Drop-in for ``SMPLX`` in regressor/human_shape/models/body_models/body_models.py:497-767:
+same constructor arguments (``model_folder``, ``ext``, ``betas.num``, ``expression.num``,
+``use_face_contour``, ``j14_regressor_path``, ...), same registered buffers (so checkpoints
+that carry ``model.*`` buffers load), same ``forward`` signature and output dict.
+
+Data layout on the device (prepared once, float64 folds done on the host):
+  * shapedirs / posedirs are stored K-contiguous and row-padded ([V*3, 32] and [V*3, 496]) so
+    that the two blend-shape sums are GEMMs on the f32 MFMA kernel with M = batch:
+        v_shaped = v_template + S c            (lbs.py:163, 218-239)  bias epilogue
+        v_posed  = v_shaped + P^T pose_feat    (lbs.py:171-182)       residual epilogue
+    posedirs (61 MB) is streamed from HBM exactly once per batch;
+  * the joint regressor is folded through the shape basis: J = J_t + (J_reg S) c, which
+    removes the [55,V] x [B,V,3] product (lbs.py:167, 199-215) from the per-batch work;
+  * lbs_weights are stored transposed [55, V] so the skinning kernel reads them coalesced.
+"""
+import os
+import os.path as osp
+import pickle
+from collections import defaultdict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _lib
+from ...utils.synthetic import keypoint_names as _smplx_keypoint_names
+from .utils import KeypointTensor, find_joint_kin_chain, to_tensor
+
+J14_NAMES = ['right_ankle', 'right_knee', 'right_hip', 'left_hip', 'left_knee', 'left_ankle',
+             'right_wrist', 'right_elbow', 'right_shoulder', 'left_shoulder', 'left_elbow',
+             'left_wrist', 'neck', 'head']
+J9_NAMES = ['right_wrist', 'right_elbow', 'right_shoulder', 'left_shoulder', 'left_elbow',
+            'left_wrist', 'spine', 'jaw ', 'head']
+
+
+def _to_np(array, dtype=np.float32):
+    if 'scipy.sparse' in str(type(array)):
+        array = array.todense()
+    return np.array(array, dtype=dtype)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class SMPLX(nn.Module):
+    NUM_BODY_JOINTS = 21
+    NUM_HAND_JOINTS = 15
+    NUM_FACE_JOINTS = 3
+    NUM_JOINTS = NUM_BODY_JOINTS + 2 * NUM_HAND_JOINTS + NUM_FACE_JOINTS
+    SHAPE_SPACE_DIM = 300
+    EXPRESSION_SPACE_DIM = 100
+    NECK_IDX = 12
+    HEAD_IDX = 15
+    NAME = 'smplx'
+
+    def __init__(self, model_folder, is_training=False, data_struct=None, betas=None,
+                 expression=None, use_face_contour=False, gender='neutral',
+                 dtype=torch.float32, ext='npz', extra_joint_path='', v_template_path='',
+                 head_verts_ids_path='', **kwargs):
+        super().__init__()
+        if dtype != torch.float32:
+            raise NotImplementedError('the HIP SMPL-X layer computes in float32')
+        if extra_joint_path:
+            raise NotImplementedError('extra_joint_path is empty in every SHAPY config')
+        if data_struct is None:
+            path = osp.join(model_folder, f'SMPLX_{gender.upper()}.{ext}')
+            if ext == 'npz':
+                data_struct = dict(np.load(path, allow_pickle=True))
+            else:
+                with open(path, 'rb') as f:
+                    data_struct = dict(pickle.load(f, encoding='latin1'))
+        ds = data_struct
+        self.gender = gender
+        self.dtype = dtype
+        self.use_face_contour = use_face_contour
+        self._num_betas = (betas or {'num': 10}).get('num', 10)
+        self._num_expression_coeffs = (expression or {'num': 10}).get('num', 10)
+
+        self.faces = _to_np(ds['f'], dtype=np.int64)
+        self.register_buffer('faces_tensor', to_tensor(self.faces, dtype=torch.long))
+        v_template_path = osp.expandvars(v_template_path or '')
+        if osp.exists(v_template_path):
+            raise NotImplementedError('v_template_path meshes need trimesh (not in this image)')
+        self.register_buffer('v_template', to_tensor(_to_np(ds['v_template'])))
+        head_verts_ids_path = osp.expandvars(head_verts_ids_path or '')
+        head_ids = np.load(head_verts_ids_path) if osp.exists(head_verts_ids_path) else []
+        self.register_buffer('head_vertices_ids', torch.tensor(head_ids, dtype=torch.long))
+
+        num_betas = min(self._num_betas, self.SHAPE_SPACE_DIM)
+        shapedirs = np.asarray(ds['shapedirs'])
+        self.register_buffer('shapedirs', to_tensor(_to_np(shapedirs[:, :, :num_betas])))
+        self.register_buffer('J_regressor', to_tensor(_to_np(ds['J_regressor'])))
+        num_pose_basis = ds['posedirs'].shape[-1]
+        posedirs = np.reshape(ds['posedirs'], [-1, num_pose_basis]).T
+        self.register_buffer('posedirs', to_tensor(_to_np(posedirs)))
+        parents = to_tensor(_to_np(ds['kintree_table'][0], dtype=np.int64), dtype=torch.long)
+        parents[0] = -1
+        self.register_buffer('parents', parents)
+        self.register_buffer('lbs_weights', to_tensor(_to_np(ds['weights'])))
+
+        self.register_buffer('lmk_faces_idx',
+                             torch.tensor(np.asarray(ds['lmk_faces_idx'], np.int64)))
+        self.register_buffer('lmk_bary_coords', to_tensor(_to_np(ds['lmk_bary_coords'])))
+        self.register_buffer('dynamic_lmk_faces_idx',
+                             torch.tensor(np.asarray(ds['dynamic_lmk_faces_idx'], np.int64)))
+        self.register_buffer('dynamic_lmk_bary_coords',
+                             to_tensor(_to_np(ds['dynamic_lmk_bary_coords'])))
+        neck_kin_chain = find_joint_kin_chain(self.HEAD_IDX, parents.tolist())
+        self.register_buffer('neck_kin_chain', torch.tensor(neck_kin_chain, dtype=torch.long))
+        e0 = self.SHAPE_SPACE_DIM
+        self.register_buffer('expr_dirs', to_tensor(_to_np(
+            shapedirs[:, :, e0:e0 + self._num_expression_coeffs])))
+
+        self._keypoint_names = self.build_keypoint_names()
+        j14_regressor_path = osp.expandvars(kwargs.get('j14_regressor_path', '') or '')
+        self.use_joint_regressor = osp.exists(j14_regressor_path)
+        if self.use_joint_regressor:
+            if j14_regressor_path.endswith('.pkl'):
+                with open(j14_regressor_path, 'rb') as f:
+                    j14 = pickle.load(f, encoding='latin1')
+            else:
+                j14 = np.load(j14_regressor_path)
+            target_names = J14_NAMES if j14.shape[0] == 14 else J9_NAMES
+            source = [i for i, n in enumerate(self.keypoint_names) if n in target_names]
+            target = [target_names.index(self.keypoint_names[i]) for i in source]
+            self.register_buffer('source_idxs', torch.tensor(source, dtype=torch.long))
+            self.register_buffer('target_idxs', torch.tensor(target, dtype=torch.long))
+            self.register_buffer('extra_joint_regressor',
+                                 torch.from_numpy(np.asarray(j14)).to(torch.float32))
+        self._dev = {}
+        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
+
+    # ---- reference properties ----
+    name = property(lambda self: self.NAME)
+    num_betas = property(lambda self: self._num_betas)
+    num_expression_coeffs = property(lambda self: self._num_expression_coeffs)
+    num_body_joints = property(lambda self: self.NUM_BODY_JOINTS)
+    num_hand_joints = property(lambda self: self.NUM_HAND_JOINTS)
+    num_joints = property(lambda self: self.J_regressor.shape[0])
+    num_verts = property(lambda self: self.v_template.shape[0])
+    keypoint_names = property(lambda self: self._keypoint_names)
+    connections = property(lambda self: None)
+    parts = property(lambda self: None)
+    part_connections = property(lambda self: None)
+
+    def get_num_verts(self):
+        return self.v_template.shape[0]
+
+    def get_num_faces(self):
+        return self.faces.shape[0]
+
+    def get_head_vertices_ids(self):
+        return self.head_vertices_ids
+
+    def build_keypoint_names(self):
+        names = _smplx_keypoint_names()
+        if not self.use_face_contour:
+            names = [n for n in names if 'contour' not in n]
+        return names
+
+    def extra_repr(self):
+        return '\n'.join([f'Gender: {self.gender.upper()}',
+                          f'Number of joints: {self.J_regressor.shape[0]}',
+                          f'Betas: {self.num_betas}',
+                          f'Number of Expression Coefficients: {self.num_expression_coeffs}',
+                          f'Use face contour: {self.use_face_contour}'])
+
+    # ---- device-side model ----
+    def invalidate(self):
+        self._dev = {}
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._dev = {}
+        return out
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st['_dev'] = {}
+        return st
+
+    def _device_model(self, device):
+        key = str(device)
+        dm = self._dev.get(key)
+        if dm is not None:
+            return dm
+        V, J = self.v_template.shape[0], self.J_regressor.shape[0]
+        nb, ne = self.shapedirs.shape[-1], self.expr_dirs.shape[-1]
+        NB = nb + ne
+        NBpad = _round_up(NB, 16)
+        P = self.posedirs.shape[0]
+        Ppad = _round_up(P, 16)
+        N = V * 3
+        Npad = _round_up(N, 128)
+        d64 = lambda t: t.detach().double().cpu()
+        S = torch.cat([d64(self.shapedirs), d64(self.expr_dirs)], dim=-1)       # V,3,NB
+        Jreg = d64(self.J_regressor)
+        J_t = Jreg @ d64(self.v_template)                                       # J,3
+        J_s = torch.einsum('jv,vkl->jkl', Jreg, S)                              # J,3,NB
+        sh_t = torch.zeros(Npad, NBpad, dtype=torch.float32)
+        sh_t[:N, :NB] = S.reshape(N, NB).float()
+        pd_t = torch.zeros(Npad, Ppad, dtype=torch.float32)
+        pd_t[:N, :P] = self.posedirs.detach().float().cpu().t()
+        f32 = lambda t: t.detach().float().contiguous().to(device)
+        i32 = lambda t: t.detach().to(torch.int32).contiguous().to(device)
+        t = dict(
+            parents=i32(self.parents), J_template=f32(J_t), J_shapedirs=f32(J_s),
+            v_template=f32(self.v_template.reshape(-1)), shapedirs_t=sh_t.to(device),
+            posedirs_t=pd_t.to(device), lbs_weights_t=f32(self.lbs_weights.t()),
+            faces=i32(self.faces_tensor), lmk_faces_idx=i32(self.lmk_faces_idx),
+            lmk_bary=f32(self.lmk_bary_coords), dyn_lmk_faces_idx=i32(self.dynamic_lmk_faces_idx),
+            dyn_lmk_bary=f32(self.dynamic_lmk_bary_coords), neck_kin_chain=i32(self.neck_kin_chain))
+        m = _lib.ShapySmplxModel()
+        m.V, m.J, m.NB, m.P, m.Ppad, m.NBpad = V, J, NB, P, Ppad, NBpad
+        m.n_static_lmk = self.lmk_faces_idx.shape[0]
+        m.n_dyn_lmk = self.dynamic_lmk_faces_idx.shape[1]
+        m.n_dyn_rows = self.dynamic_lmk_faces_idx.shape[0]
+        m.n_neck = self.neck_kin_chain.shape[0]
+        for k, v in t.items():
+            setattr(m, k, v.data_ptr())
+        dm = dict(struct=m, tensors=t, V=V, J=J, NB=NB, NBpad=NBpad, P=P, Ppad=Ppad, nb=nb, ne=ne)
+        self._dev[key] = dm
+        return dm
+
+    def _gemm(self, lib, stream, inp, K, wgt, N, out, bias=None, res=None):
+        d = _lib.ShapyConv()
+        d.in_ = inp.data_ptr(); d.wgt = wgt.data_ptr()
+        d.bias = bias.data_ptr() if bias is not None else None
+        d.res = res.data_ptr() if res is not None else None
+        d.out = out.data_ptr()
+        d.B = inp.shape[0]; d.Hi = d.Wi = d.Ho = d.Wo = 1
+        d.Cin = K; d.in_ld = K; d.Cout = N
+        d.ksize = 1; d.stride = 1; d.pad = 0
+        d.out_ld = N; d.out_coff = 0; d.res_ld = N; d.res_coff = 0
+        d.relu = 0; d.ups = 1; d.tile = 0
+        _lib.check(lib.shapy_conv2d_f32(ctypes_byref(d), stream), 'shapy_conv2d_f32 (blend shapes)')
+
+    def forward_shape(self, betas=None):
+        """SMPL.forward_shape (body_models.py:296-306)."""
+        out = self.forward(betas=betas, get_skin=False, return_shaped=True, _shape_only=True)
+        return {'vertices': out['v_shaped'], 'betas': betas, 'v_shaped': out['v_shaped']}
+
+    def forward(self, global_rot=None, body_pose=None, left_hand_pose=None, right_hand_pose=None,
+                jaw_pose=None, betas=None, expression=None, transl=None, leye_pose=None,
+                reye_pose=None, get_skin=True, return_full_pose=False, return_shaped=True,
+                _shape_only=False, **kwargs):
+        """SMPLX.forward (body_models.py:628-767): poses are rotation matrices [B,k,3,3]."""
+        device = self.shapedirs.device
+        _lib.require_cuda(self.shapedirs, 'SMPLX buffers')
+        lib = _lib.load()
+        stream = _lib.current_stream()
+        model_vars = [betas, global_rot, body_pose, transl, left_hand_pose, right_hand_pose,
+                      jaw_pose, leye_pose, reye_pose, expression]
+        B = 1
+        for var in model_vars:
+            if var is not None:
+                B = max(B, len(var))
+        dm = self._device_model(device)
+        m = dm['struct']
+        V, J = dm['V'], dm['J']
+        f32 = dict(dtype=torch.float32, device=device)
+
+        def eye(n):
+            return torch.eye(3, **f32).view(1, 1, 3, 3).expand(B, n, -1, -1)
+        parts = [(global_rot, 1), (body_pose, self.NUM_BODY_JOINTS), (jaw_pose, 1),
+                 (leye_pose, 1), (reye_pose, 1), (left_hand_pose, self.NUM_HAND_JOINTS),
+                 (right_hand_pose, self.NUM_HAND_JOINTS)]
+        full_pose = torch.cat([eye(n) if p is None else p.reshape(-1, n, 3, 3).to(**f32)
+                               for p, n in parts], dim=1).contiguous()
+        if betas is None:
+            betas = torch.zeros([B, self.num_betas], **f32)
+        coeffs = torch.zeros(B, dm['NBpad'], **f32)
+        coeffs[:, :dm['nb']] = betas
+        if expression is not None:
+            coeffs[:, dm['nb']:dm['NB']] = expression
+
+        N = V * 3
+        v_shaped_full = torch.empty(B, V, 3, **f32)
+        self._gemm(lib, stream, coeffs, dm['NBpad'], dm['tensors']['shapedirs_t'], N, v_shaped_full,
+                   bias=dm['tensors']['v_template'])
+        if expression is None:
+            v_shaped = v_shaped_full
+        else:
+            cb = coeffs.clone()
+            cb[:, dm['nb']:] = 0
+            v_shaped = torch.empty(B, V, 3, **f32)
+            self._gemm(lib, stream, cb, dm['NBpad'], dm['tensors']['shapedirs_t'], N, v_shaped,
+                       bias=dm['tensors']['v_template'])
+        output = defaultdict(lambda: None, faces=self.faces)
+        if return_shaped:
+            output['v_shaped'] = v_shaped
+        if _shape_only:
+            return output
+
+        rot = torch.empty(B, J, 3, 3, **f32)
+        pf = torch.empty(B, dm['Ppad'], **f32)
+        A = torch.empty(B, J, 12, **f32)
+        posed = torch.empty(B, J, 3, **f32)
+        dyn_row = torch.empty(B, dtype=torch.int32, device=device)
+        _lib.check(lib.shapy_smplx_pose_f32(
+            ctypes_byref(m), _lib.ptr(full_pose), _lib.POSE_ROTMAT, J, _lib.ptr(coeffs),
+            _lib.ptr(rot), _lib.ptr(pf), _lib.ptr(A), _lib.ptr(posed), _lib.ptr(dyn_row), B,
+            stream), 'shapy_smplx_pose_f32')
+        v_posed = torch.empty(B, V, 3, **f32)
+        self._gemm(lib, stream, pf, dm['Ppad'], dm['tensors']['posedirs_t'], N, v_posed,
+                   res=v_shaped_full)
+        vertices = torch.empty(B, V, 3, **f32)
+        _lib.check(lib.shapy_smplx_skin_f32(ctypes_byref(m), _lib.ptr(A), _lib.ptr(v_posed),
+                                            _lib.ptr(vertices), B, stream), 'shapy_smplx_skin_f32')
+        n_out = J + m.n_static_lmk + (m.n_dyn_lmk if self.use_face_contour else 0)
+        joints = torch.empty(B, n_out, 3, **f32)
+        _lib.check(lib.shapy_smplx_joints_f32(
+            ctypes_byref(m), _lib.ptr(posed), _lib.ptr(vertices), _lib.ptr(dyn_row), None,
+            _lib.ptr(joints), None, None, B, int(self.use_face_contour), stream),
+            'shapy_smplx_joints_f32')
+
+        if self.use_joint_regressor:
+            Jn = self.extra_joint_regressor.shape[0]
+            reg = torch.empty(B, Jn, 3, **f32)
+            _lib.check(lib.shapy_joint_regress_f32(
+                _lib.ptr(self.extra_joint_regressor.contiguous()), _lib.ptr(vertices),
+                _lib.ptr(reg), B, V, Jn, stream), 'shapy_joint_regress_f32')
+            joints[:, self.source_idxs] = reg[:, self.target_idxs]
+        if transl is not None:
+            joints += transl.unsqueeze(dim=1)
+            vertices += transl.unsqueeze(dim=1)
+
+        output['joints'] = KeypointTensor(
+            joints, source=self.name, keypoint_names=self.keypoint_names,
+            part_indices=self.parts, connections=self.connections,
+            part_connections=self.part_connections)
+        if get_skin:
+            output['vertices'] = vertices
+        if return_full_pose:
+            output['full_pose'] = full_pose
+        return output
+
+
+def ctypes_byref(x):
+    import ctypes
+    return ctypes.byref(x)

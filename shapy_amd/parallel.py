@@ -1,0 +1,78 @@
+"""Data parallelism of the hot path over the GPUs of one node.
+
+Images are independent, BatchNorm is in eval mode and the weights (418 MB) and SMPL-X
+buffers (65 MB) are replicated, so the forward pass needs NO exchange: every rank (one
+process per GPU) runs a contiguous shard of the batch.  The only collective is the
+all-gather of the predicted betas ([B_local, 10] float32 = 1,280 B per rank at bs=256/8)
+at the end of a step -- latency-bound, so it is issued as ONE RCCL all_gather on a side
+stream and overlaps the tail of the step (the measurement kernels).
+
+The reference has no data-parallel inference at all (rank > 0 returns immediately in its
+evaluator, regressor/human_shape/evaluation.py:641-642; the only collective it executes is
+a barrier, regressor/evaluate.py:100-105) -- this is new functionality asked for by the
+north star, shaped for xGMI: one tiny collective per step, nothing bucketed.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """Contiguous split of n items: the first n % world ranks get one extra item."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def init_distributed(backend='nccl'):
+    """env:// rendezvous as in regressor/evaluate.py:68-79 (backend "nccl" is RCCL on ROCm)."""
+    import os
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if not dist.is_initialized():
+        dist.init_process_group(backend, init_method='env://')
+    return dist.get_rank(), dist.get_world_size()
+
+
+class BetasGatherer:
+    """all_gather of equally sized per-rank tensors, issued on a side stream on GPUs."""
+
+    def __init__(self, world=None, group=None):
+        self.group = group
+        self.world = world if world is not None else (
+            dist.get_world_size(group) if dist.is_initialized() else 1)
+        self._stream = None
+
+    def __call__(self, local):
+        if self.world == 1:
+            return local
+        local = local.contiguous()
+        out = local.new_empty((self.world * local.shape[0],) + tuple(local.shape[1:]))
+        if local.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            self._stream.wait_stream(cur)
+            with torch.cuda.stream(self._stream):
+                dist.all_gather_into_tensor(out, local, group=self.group)
+            local.record_stream(self._stream)
+            cur.wait_stream(self._stream)
+        else:
+            chunks = list(out.chunk(self.world, dim=0))
+            dist.all_gather(chunks, local, group=self.group)
+        return out
+
+
+def gather_variable(local, group=None):
+    """all_gather for shards of different length (last ranks may hold one item less)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes)
+    pad = local.new_zeros((m,) + tuple(local.shape[1:]))
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)

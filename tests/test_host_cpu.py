@@ -1,0 +1,227 @@
+"""CPU-only tests of the host side: config system, C-ABI symbols, plan builder, DP helpers."""
+import os
+import os.path as osp
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
+
+
+# ---- config -------------------------------------------------------------------------------
+def test_config_defaults_yaml_dotlist():
+    from shapy_amd.config import merge_config, default_config, ConfigNode
+    cfg = merge_config([osp.join(ROOT, 'configs/b2a_expose_hrnet_demo.yaml')],
+                       ['network.smplx.num_stages=2', 'output_folder=/tmp/x',
+                        'datasets.pose.transforms.crop_size=224'])
+    assert cfg.network.type == 'SMPLXRegressor'
+    assert cfg.network.smplx.num_stages == 2 and cfg.output_folder == '/tmp/x'
+    assert cfg.network.smplx.get('feature_key') == 'concat'
+    assert cfg.network.smplx.mlp.activation.type == 'none'            # yaml over default
+    assert cfg.network.smplx.mlp.activation.inplace is True           # default survives merge
+    assert cfg.body_model.smplx.use_face_contour is True
+    assert cfg.network.smplx.backbone.hrnet.stage3.num_channels == [48, 96, 192]
+    assert cfg.datasets.pose.transforms.crop_size == 224
+    assert default_config().datasets.pose.transforms.crop_size == 256   # reference default
+    d = dict(**cfg.network.smplx.camera)                                # ** splatting works
+    assert d['pos_func'] == 'softplus'
+    with pytest.raises(AttributeError):
+        cfg.network.nonexistent
+    c2 = cfg.copy()
+    c2.network.smplx.num_stages = 5
+    assert cfg.network.smplx.num_stages == 2
+    assert isinstance(cfg.network.smplx, ConfigNode)
+
+
+def test_cmd_parser():
+    from shapy_amd.config import parse_args
+    cfg = parse_args(['--exp-cfg', osp.join(ROOT, 'configs/b2a_expose_hrnet_eval_shape.yaml'),
+                      '--exp-opts', 'use_cuda=False', '--num-gpus', '8', '--backend', 'gloo'])
+    assert cfg.num_gpus == 8 and cfg.backend == 'gloo' and cfg.use_cuda is False
+
+
+# ---- C-ABI --------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from shapy_amd import _lib
+    hdr = open(osp.join(ROOT, 'include', 'shapy_hip.h')).read()
+    declared = set(re.findall(r'\b(shapy_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.shapy_abi_version() == 1
+    assert lib.shapy_build_arch() == b'gfx950'
+    # struct layouts agree with the C header (sizeof through a tiny C program)
+    src = '#include <stdio.h>\n#include "shapy_hip.h"\nint main(){printf("%zu %zu %zu", ' \
+          'sizeof(ShapyConv), sizeof(ShapyOp), sizeof(ShapySmplxModel));return 0;}'
+    exe = '/tmp/shapy_sizeof'
+    subprocess.run(['gcc', '-x', 'c', '-', '-I', osp.join(ROOT, 'include'), '-o', exe],
+                   input=src.encode(), check=True)
+    sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    import ctypes
+    assert sizes == [ctypes.sizeof(_lib.ShapyConv), ctypes.sizeof(_lib.ShapyOp),
+                     ctypes.sizeof(_lib.ShapySmplxModel)]
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from shapy_amd._lib import ShapyHipError
+    from shapy_amd.models.common.pose_utils import ContinuousRotReprDecoder
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(ShapyHipError):
+        ContinuousRotReprDecoder(1)(torch.zeros(1, 6))
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for dp, _, files in os.walk(osp.join(ROOT, 'shapy_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                txt = open(osp.join(dp, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', txt, re.M):
+                    bad.append(osp.join(dp, f))
+    assert not bad, bad
+
+
+# ---- HRNet plan ---------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def hrnet():
+    from shapy_amd.config import default_config
+    from shapy_amd.models.backbone.hrnet import HighResolutionNet
+    return HighResolutionNet(default_config().network.smplx.backbone.hrnet)
+
+
+def test_plan_macs_match_survey(hrnet):
+    P = hrnet._build_plan(224, 224)
+    macs = sum(o['Ho'] * o['Wo'] * o['Cout'] * o['Cin'] * o['ksize'] ** 2
+               for o in P.ops if o['type'] != 2)
+    assert macs == 18_466_524_160           # SURVEY.md 8(d), hooked from the reference module
+    assert sum(1 for o in P.ops if o['type'] == 0) == 330 and len(P.ops) == 332
+    P256 = hrnet._build_plan(256, 256)
+    macs256 = sum(o['Ho'] * o['Wo'] * o['Cout'] * o['Cin'] * o['ksize'] ** 2
+                  for o in P256.ops if o['type'] != 2)
+    assert abs(2 * macs256 / 1e9 - 48.239) < 0.01
+
+
+def test_plan_buffers_never_alias_while_live(hrnet):
+    """Replays the op list with the executor's concurrency model: inside an epoch, ops of
+    different lanes are unordered.  A buffer being written must not overlap any other buffer
+    that is still live (written earlier and read later, or touched in the same epoch by
+    another lane)."""
+    P = hrnet._build_plan(64, 64)
+    total = P.allocate()
+    bufs = [b for b in P.bufs if b.uses]
+    for b in bufs:
+        assert b.off % 4 == 0 and b.off + b.size <= total
+    epoch_of, e = [], 0
+    for o in P.ops:
+        if o['barrier_before']:
+            e += 1
+        epoch_of.append(e)
+    # live interval of a buffer in (epoch, lane, op) terms
+    for i, a in enumerate(bufs):
+        for b in bufs[i + 1:]:
+            if a.off + a.size <= b.off or b.off + b.size <= a.off:
+                continue
+            ea = sorted(a.uses); eb = sorted(b.uses)
+            ka = {(u[0], u[1]) for u in a.uses}; kb = {(u[0], u[1]) for u in b.uses}
+            if len(ka) == 1 and ka == kb:
+                # same (epoch, lane): ordered by op index on one stream
+                assert max(u[2] for u in a.uses) < min(u[2] for u in b.uses) or \
+                    max(u[2] for u in b.uses) < min(u[2] for u in a.uses)
+            else:
+                assert ea[-1][0] < eb[0][0] or eb[-1][0] < ea[0][0], (a.uses, b.uses)
+    assert total * 4 / 1e6 < 3.0            # MB per 64x64 image: liveness packing works
+
+
+def test_bn_fold_matches_conv_bn_eval():
+    from shapy_amd.models.backbone.hrnet import _fold
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(8, 6, 3, 2, 1, bias=True)
+    bn = torch.nn.BatchNorm2d(6).eval()
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 1.5)
+    bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_()
+    w, b = _fold(conv, bn)
+    x = torch.randn(2, 8, 9, 9)
+    ref = bn(conv(x))
+    w_oihw = torch.from_numpy(w).permute(0, 3, 1, 2)
+    out = torch.nn.functional.conv2d(x, w_oihw, torch.from_numpy(b), 2, 1)
+    assert (ref - out).abs().max() < 1e-5
+
+
+def test_regressor_collapse_is_the_same_affine_map():
+    from shapy_amd.models.common.networks import MLP
+    torch.manual_seed(0)
+    mlp = MLP(2193, 145, layers=[1024, 1024], activation={'type': 'none'},
+              normalization={'type': 'none'}, dropout=0.5, gain=0.3).eval()
+    assert sorted(mlp.state_dict()) == ['layer_000.0.bias', 'layer_000.0.weight',
+                                        'layer_001.0.bias', 'layer_001.0.weight',
+                                        'output_layer.bias', 'output_layer.weight']
+    W, b = mlp.collapse()
+    x = torch.randn(3, 2193, dtype=torch.float64)
+    y = x
+    for lin in mlp.linears():
+        y = y @ lin.weight.double().t() + lin.bias.double()
+    assert (x @ W.t() + b - y).abs().max() < 1e-9
+    with pytest.raises(NotImplementedError):
+        MLP(8, 4, layers=[8], activation={'type': 'relu'}, normalization={'type': 'none'}).collapse()
+
+
+def test_full_module_state_dict_layout(golden_dir):
+    """Same keys and shapes as the reference SMPLXRegressor (checkpoint compatibility)."""
+    import __graft_entry__ as ge
+    net, _ = ge.make_network(device='cpu')
+    ref = {}
+    with open(osp.join(golden_dir, 'state_dict_keys.txt')) as f:
+        for line in f:
+            k, s = line.strip().split(' ', 1)
+            ref[k] = tuple(eval(s))
+    mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert mine == ref
+    assert net.param_mean.shape == (1, 145)
+    assert net.betas_idxs.tolist() == list(range(132, 142))
+    import copy
+    net2 = copy.deepcopy(net)          # the reference's Evaluator deep-copies the model
+    assert sorted(net2.state_dict()) == sorted(net.state_dict())
+
+
+# ---- data parallel helpers (gloo, world_size 2) -----------------------------------------------
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from shapy_amd import parallel
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    r, w = parallel.init_distributed('gloo')
+    n = 7
+    a, b = parallel.shard_range(n, r, w)
+    full = torch.arange(n * 10, dtype=torch.float32).view(n, 10)
+    g = parallel.gather_variable(full[a:b])
+    ok1 = torch.equal(g, full)
+    eq = parallel.BetasGatherer(w)(full[r * 3:(r + 1) * 3])
+    ok2 = torch.equal(eq, full[:6])
+    q.put((rank, ok1, ok2, (a, b)))
+    dist.destroy_process_group()
+
+
+def test_dp_sharding_and_allgather_gloo():
+    import torch.multiprocessing as mp
+    from shapy_amd.parallel import shard_range
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [shard_range(256, r, 8) for r in range(8)][-1] == (224, 256)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] and r[2] for r in res), res
+    assert sorted(r[3] for r in res) == [(0, 4), (4, 7)]
