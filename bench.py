@@ -49,9 +49,7 @@ def cpu_baseline(batch, size, budget_s=15.0):
     cores = torch.get_num_threads()
     b = min(batch, 8)
     x = syn.synthetic_images(b, size, 1)
-    ge.oracle_forward(x, with_measurements=True)           # warm-up (builds weights, pages in)
-    n, t0 = 0, time.perf_counter()
-    # weights are regenerated inside oracle_forward; time only the forward passes
+    n = 0
     import oracle.hrnet_torch as ht
     from oracle import body_np, measure
     sd = syn.synthetic_state_dict([('backbone.' + k, s) for k, s in ht.state_dict_spec()], 0)
@@ -69,6 +67,8 @@ def cpu_baseline(batch, size, budget_s=15.0):
     lm = measure.load_landmarks(osp.join(data, 'measurement_defitions.yaml'),
                                 osp.join(data, 'smplx_measurements.yaml'))
     xt = torch.from_numpy(x)
+    with torch.no_grad():                                   # untimed warm-up pass
+        ht.hrnet_forward(sd, xt, prefix='backbone.')
     t0 = time.perf_counter()
     while True:
         with torch.no_grad():

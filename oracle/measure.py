@@ -88,7 +88,7 @@ def plane_triangles(height):
     verts = np.tile(np.array([[-1., 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], f32), (B, 1, 1))
     verts[:, :, 1] = height.reshape(B, 1)
     faces = np.array([[0, 1, 2], [0, 2, 3]])
-    return verts[:, faces]
+    return np.ascontiguousarray(verts[:, faces])
 
 
 def compute_mass(tris):

@@ -53,7 +53,12 @@ class ShapySmplxModel(ctypes.Structure):
 OP_CONV, OP_STEM, OP_MEANPOOL = 0, 1, 2
 POSE_ROTMAT, POSE_CONT6D, POSE_AXIS_ANGLE = 0, 1, 2
 TILES = {'auto': 0, '256x48': 1, '128x96': 2, '128x128': 3, '256x64': 4, '64x48': 5,
-         '64x96': 6, '64x128': 7, '64x64': 8}
+         '64x96': 6, '64x128': 7, '64x64': 8, '128x48': 9, '128x64': 10, '256x96': 11,
+         '256x128': 12}
+for _k, _v in list(TILES.items()):      # tuning knobs: XCD-contiguous order, BK = 32
+    TILES[_k + '+swz'] = _v | 0x100
+    TILES[_k + '+bk32'] = _v | 0x200
+    TILES[_k + '+swz+bk32'] = _v | 0x300
 
 #: every symbol include/shapy_hip.h declares: (restype, argtypes)
 SIGNATURES = {
@@ -95,6 +100,10 @@ def load(build_if_missing=False):
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: libshapy_hip.so has to bind to the SAME HIP runtime
+    # (libamdhip64) instance torch uses, otherwise its streams / device pointers are foreign
+    # to our launches (observed: hipErrorNoDevice when our library was loaded first).
+    import torch  # noqa: F401
     if not osp.exists(LIB_PATH):
         if build_if_missing:
             from . import build as _build

@@ -19,6 +19,10 @@ enum {
   SHAPY_TILE_64x96 = 6,
   SHAPY_TILE_64x128 = 7,
   SHAPY_TILE_64x64 = 8,
+  SHAPY_TILE_128x48 = 9,
+  SHAPY_TILE_128x64 = 10,
+  SHAPY_TILE_256x96 = 11,
+  SHAPY_TILE_256x128 = 12,
 };
 
 int conv2d_f32(const ShapyConv &d, hipStream_t s);

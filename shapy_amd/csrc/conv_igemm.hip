@@ -16,33 +16,45 @@
 
 namespace shapy {
 
-constexpr int LDS_LD = 20;   // floats per staged row: 16 + 4 pad (keeps b128 alignment)
 
 struct ConvK {
   const float *in, *wgt, *bias, *res;
   float *out;
   int M, Hi, Wi, Cin, in_ld, Ho, Wo, Cout, ks, stride, pad;
-  int out_ld, out_coff, res_ld, res_coff, relu, ups;
+  int out_ld, out_coff, res_ld, res_coff, relu, ups, swz, nbx, nby;
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int UPS, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  constexpr int AR = BM / 64;            // A rows staged per thread
-  constexpr int BR = (BN + 63) / 64;     // B rows staged per thread (guarded)
+  static_assert(BK == 16 || BK == 32, "K chunk");
+  constexpr int LDS_LD = BK + 4;         // floats per staged row (+4 pad keeps b128 alignment)
+  constexpr int KQ = BK / 4;             // float4 per staged row
+  constexpr int RPP = 256 / KQ;          // rows staged per pass of the 256 threads
+  constexpr int AR = BM / RPP;           // A rows staged per thread
+  constexpr int BR = (BN + RPP - 1) / RPP;   // B rows staged per thread (guarded)
   __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_LD];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
-  const int kq = t & 3, lrow = t >> 2;
+  // workgroup -> tile.  Workgroup ids are dealt round-robin to the 8 XCDs (private L2s): with
+  // swz every XCD gets a CONTIGUOUS run of tiles (n fastest, then m), so the tiles that share
+  // A rows -- the N tiles of one M tile and the 3x3 halos of neighbouring M tiles -- hit the
+  // same L2.  Speed only; correctness does not depend on the placement.
+  int wg = blockIdx.x;
+  if (p.swz) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int m_blk = (wg / p.nbx) * BM, n_blk = (wg % p.nbx) * BN;
+  const int kq = t % KQ, lrow = t / KQ;
 
   // ---- per-thread staging addresses ----
   int a_off[AR], a_h[AR], a_w[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const int m = m_blk + lrow + 64 * i;
+    const int m = m_blk + lrow + RPP * i;
     const int mm = m < p.M ? m : 0;
     const int wo = mm % p.Wo;
     const int tq = mm / p.Wo;
@@ -58,18 +70,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
   bool b_ok[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
-    const int r = lrow + 64 * i;
+    const int r = lrow + RPP * i;
     const int n = n_blk + r;
     b_ok[i] = (r < BN) && (n < p.Cout);
     b_off[i] = (b_ok[i] ? n : 0) * Kw + kq * 4;
   }
 
   float4 a_reg[AR], b_reg[BR];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // chunk iterator state for the NEXT chunk to be fetched
   int kh = 0, kw = 0, c0 = 0;
-  const int n_chunks = p.ks * p.ks * (p.Cin >> 4);
+  const int n_chunks = p.ks * p.ks * (p.Cin / BK);
 
   auto gload = [&]() {
     const int tap_in = (kh * p.Wi + kw) * p.in_ld + c0;
@@ -78,12 +89,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
     for (int i = 0; i < AR; ++i) {
       const bool ok = (unsigned)(a_h[i] + kh) < (unsigned)p.Hi &&
                       (unsigned)(a_w[i] + kw) < (unsigned)p.Wi;
-      a_reg[i] = ok ? *reinterpret_cast<const float4 *>(p.in + (a_off[i] + tap_in)) : zero4;
+      // out-of-image taps read the tensor base (always valid memory) and are zeroed by a data
+      // select -- selecting between a global and a private address would force flat loads
+      const float4 v = *reinterpret_cast<const float4 *>(p.in + (ok ? a_off[i] + tap_in : kq * 4));
+      a_reg[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     }
 #pragma unroll
-    for (int i = 0; i < BR; ++i)
-      b_reg[i] = b_ok[i] ? *reinterpret_cast<const float4 *>(p.wgt + (b_off[i] + tap_w)) : zero4;
-    c0 += 16;
+    for (int i = 0; i < BR; ++i) {
+      const float4 v = *reinterpret_cast<const float4 *>(p.wgt + (b_off[i] + tap_w));
+      b_reg[i] = make_float4(b_ok[i] ? v.x : 0.f, b_ok[i] ? v.y : 0.f, b_ok[i] ? v.z : 0.f,
+                             b_ok[i] ? v.w : 0.f);
+    }
+    c0 += BK;
     if (c0 == p.Cin) {
       c0 = 0;
       if (++kw == p.ks) { kw = 0; ++kh; }
@@ -94,11 +111,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
     float *Bt = lds[buf] + BM * LDS_LD;
 #pragma unroll
     for (int i = 0; i < AR; ++i)
-      *reinterpret_cast<float4 *>(A + (lrow + 64 * i) * LDS_LD + kq * 4) = a_reg[i];
+      *reinterpret_cast<float4 *>(A + (lrow + RPP * i) * LDS_LD + kq * 4) = a_reg[i];
 #pragma unroll
     for (int i = 0; i < BR; ++i)
-      if (lrow + 64 * i < BN)
-        *reinterpret_cast<float4 *>(Bt + (lrow + 64 * i) * LDS_LD + kq * 4) = b_reg[i];
+      if (lrow + RPP * i < BN)
+        *reinterpret_cast<float4 *>(Bt + (lrow + RPP * i) * LDS_LD + kq * 4) = b_reg[i];
   };
 
   f32x4 acc[TM][TN];
@@ -120,80 +137,146 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
     const bool more = kc + 1 < n_chunks;
     if (more) gload();
     const float *L = lds[cur];
-    float4 af[TM], bf[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-      af[i] = *reinterpret_cast<const float4 *>(L + a_base + i * 16 * LDS_LD);
+    for (int sub = 0; sub < BK / 16; ++sub) {
+      f32x4 af[TM], bf[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-      bf[j] = *reinterpret_cast<const float4 *>(L + b_base + j * 16 * LDS_LD);
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const f32x4 *>(L + a_base + i * 16 * LDS_LD + sub * 16);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *reinterpret_cast<const f32x4 *>(L + b_base + j * 16 * LDS_LD + sub * 16);
+      // k-step outermost: consecutive MFMAs hit different accumulators (the 16x16x4 f32 MFMA
+      // has a 40-cycle dependent latency vs a 32-cycle issue interval)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-      }
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    }
     if (more) lstore(cur ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue: bias (+ residual) (+ ReLU), plain or upsample-scatter store ----
+  // `res` may alias `out` (in-place accumulation of the fuse layers), so a residual load may
+  // not be scheduled across an earlier store by the compiler: issue ALL residual loads of a
+  // group first, then all stores.
   const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+  const int row0 = m_blk + wm * (BM / WM) + row_l;
+  const int col0 = n_blk + wn * (BN / WN) + col_l;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int col = n_blk + wn * (BN / WN) + j * 16 + col_l;
-    if (col >= p.Cout) continue;
-    const float bias = p.bias ? p.bias[col] : 0.f;
+    const int col = col0 + j * 16;
+    const float bias = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m_blk + wm * (BM / WM) + i * 16 + row_l + r;
-        if (row >= p.M) continue;
-        const float v = acc[i][j][r] + bias;
-        if (p.ups == 1) {
-          float o = v;
-          if (p.res) o += p.res[(long)row * p.res_ld + p.res_coff + col];
-          if (p.relu) o = fmaxf(o, 0.f);
-          p.out[(long)row * p.out_ld + p.out_coff + col] = o;
-        } else {
-          const int wo = row % p.Wo;
-          const int tq = row / p.Wo;
-          const int ho = tq % p.Ho;
-          const int b = tq / p.Ho;
-          const int WoU = p.Wo * p.ups;
-          const long pix0 = ((long)(b * p.Ho + ho) * p.ups) * WoU + (long)wo * p.ups;
-          for (int dy = 0; dy < p.ups; ++dy)
-            for (int dx = 0; dx < p.ups; ++dx) {
-              const long pix = pix0 + (long)dy * WoU + dx;
-              float o = v;
-              if (p.res) o += p.res[pix * p.res_ld + p.res_coff + col];
-              if (p.relu) o = fmaxf(o, 0.f);
-              p.out[pix * p.out_ld + p.out_coff + col] = o;
-            }
-        }
+      for (int r = 0; r < 4; ++r) acc[i][j][r] += bias;
+  }
+  if constexpr (UPS == 1) {
+    if (p.res) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = col0 + j * 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = row0 + i * 16 + r;
+            if (col < p.Cout && row < p.M)
+              acc[i][j][r] += p.res[(long)row * p.res_ld + p.res_coff + col];
+          }
       }
     }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = col0 + j * 16;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + i * 16 + r;
+          if (col < p.Cout && row < p.M) {
+            const float o = p.relu ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
+            p.out[(long)row * p.out_ld + p.out_coff + col] = o;
+          }
+        }
+    }
+  } else {
+    // conv1x1 + BN + nearest Upsample(UPS) + add (+ ReLU): every computed value goes to a
+    // UPS x UPS block of output pixels; residual loads are batched RG rows at a time
+    constexpr int RG = UPS >= 4 ? 16 / UPS : UPS;     // UPS 2 -> 2, 4 -> 4, 8 -> 2 rows
+    const int WoU = p.Wo * UPS;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + i * 16 + r;
+        if (row >= p.M) continue;
+        const int wo = row % p.Wo;
+        const int tq = row / p.Wo;
+        const int ho = tq % p.Ho;
+        const int b = tq / p.Ho;
+        const long pix0 = ((long)(b * p.Ho + ho) * UPS) * WoU + (long)wo * UPS;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = col0 + j * 16;
+          if (col >= p.Cout) continue;
+          const float v = acc[i][j][r];
+          const float *rp = p.res ? p.res + pix0 * p.res_ld + p.res_coff + col : nullptr;
+          float *op = p.out + pix0 * p.out_ld + p.out_coff + col;
+#pragma unroll
+          for (int dy0 = 0; dy0 < UPS; dy0 += RG) {
+            float tmp[RG * UPS];
+#pragma unroll
+            for (int q = 0; q < RG * UPS; ++q)
+              tmp[q] = rp ? rp[((long)(dy0 + q / UPS) * WoU + q % UPS) * p.res_ld] : 0.f;
+#pragma unroll
+            for (int q = 0; q < RG * UPS; ++q) {
+              const float o = v + tmp[q];
+              op[((long)(dy0 + q / UPS) * WoU + q % UPS) * p.out_ld] = p.relu ? fmaxf(o, 0.f) : o;
+            }
+          }
+        }
+      }
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch(const ConvK &k, hipStream_t s) {
-  dim3 grid((k.Cout + BN - 1) / BN, (k.M + BM - 1) / BM);
-  hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, k);
+template <int BM, int BN, int WM, int WN, int UPS = 1, int BK = 16>
+static int launch(ConvK k, hipStream_t s) {
+  k.nbx = (k.Cout + BN - 1) / BN;
+  k.nby = (k.M + BM - 1) / BM;
+  hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, UPS, BK>), dim3(k.nbx * k.nby), dim3(256),
+                     0, s, k);
   return (int)hipGetLastError();
 }
 
+// the upsample-scatter epilogue and the BK = 32 variant are instantiated for the two small tiles
+template <int BM, int BN, int WM, int WN>
+static int launch_small(const ConvK &k, int bk, hipStream_t s) {
+  if (bk == 32 && k.ups == 1 && (k.Cin & 31) == 0) return launch<BM, BN, WM, WN, 1, 32>(k, s);
+  switch (k.ups) {
+    case 1: return launch<BM, BN, WM, WN, 1>(k, s);
+    case 2: return launch<BM, BN, WM, WN, 2>(k, s);
+    case 4: return launch<BM, BN, WM, WN, 4>(k, s);
+    case 8: return launch<BM, BN, WM, WN, 8>(k, s);
+    default: return SHAPY_EINVAL;
+  }
+}
+
 int conv_tile_auto(int M, int Cout) {
-  // wave tile is 64x48 / 64x64 for large M, 32x48 / 32x64 when M is small
-  const bool n96 = (Cout % 96 == 0) || (Cout % 48 == 0 && Cout > 48) || (Cout % 64 != 0 && Cout > 128);
-  if (Cout <= 48) return M >= 8192 ? SHAPY_TILE_256x48 : SHAPY_TILE_64x48;
-  if (n96) return M >= 16384 ? SHAPY_TILE_128x96 : SHAPY_TILE_64x96;
-  if (Cout <= 64) return M >= 8192 ? SHAPY_TILE_256x64 : SHAPY_TILE_64x64;
-  return M >= 16384 ? SHAPY_TILE_128x128 : SHAPY_TILE_64x128;
+  // Measured on MI355X at B = 64 (tools/conv_bench.py, profiles/conv_bench_r01.txt): the
+  // kernel is latency-bound, so the smallest tiles (wave tile 16x48 / 32x32, 8 waves per
+  // SIMD) beat the large ones on every HRNet class.  Choose the N tile (48 or 64) that pads
+  // Cout least; on a tie take 64 unless that leaves too few workgroups to fill 256 CUs.
+  const long mt = (M + 63) / 64;
+  const int p48 = (Cout + 47) / 48 * 48, p64 = (Cout + 63) / 64 * 64;
+  if (p48 < p64) return SHAPY_TILE_64x48;
+  if (p64 < p48) return SHAPY_TILE_64x64;
+  return mt * (p64 / 64) >= 512 ? SHAPY_TILE_64x64 : SHAPY_TILE_64x48;
 }
 
 int conv2d_f32(const ShapyConv &d, hipStream_t s) {
@@ -208,16 +291,26 @@ int conv2d_f32(const ShapyConv &d, hipStream_t s) {
   k.out_ld = d.out_ld; k.out_coff = d.out_coff; k.res_ld = d.res_ld; k.res_coff = d.res_coff;
   k.relu = d.relu; k.ups = d.ups;
   if (k.M <= 0 || k.Cout <= 0) return SHAPY_OK;
-  const int tile = d.tile ? d.tile : conv_tile_auto(k.M, k.Cout);
+  // d.tile: low byte = SHAPY_TILE_* (0 = auto), 0x100 = XCD-contiguous workgroup order,
+  // 0x200 = BK 32 (tuning knobs of tools/conv_bench.py)
+  k.swz = (d.tile & 0x100) ? 1 : 0;
+  const int bk = (d.tile & 0x200) ? 32 : 16;
+  int tile = (d.tile & 0xff) ? (d.tile & 0xff) : conv_tile_auto(k.M, k.Cout);
+  if (k.ups != 1 && tile != SHAPY_TILE_64x48 && tile != SHAPY_TILE_64x64)
+    tile = (k.Cout % 64 == 0 && k.Cout % 48 != 0) ? SHAPY_TILE_64x64 : SHAPY_TILE_64x48;
   switch (tile) {
     case SHAPY_TILE_256x48: return launch<256, 48, 4, 1>(k, s);
     case SHAPY_TILE_128x96: return launch<128, 96, 2, 2>(k, s);
     case SHAPY_TILE_128x128: return launch<128, 128, 2, 2>(k, s);
     case SHAPY_TILE_256x64: return launch<256, 64, 4, 1>(k, s);
-    case SHAPY_TILE_64x48: return launch<64, 48, 4, 1>(k, s);
+    case SHAPY_TILE_64x48: return launch_small<64, 48, 4, 1>(k, bk, s);
     case SHAPY_TILE_64x96: return launch<64, 96, 2, 2>(k, s);
     case SHAPY_TILE_64x128: return launch<64, 128, 2, 2>(k, s);
-    case SHAPY_TILE_64x64: return launch<64, 64, 2, 2>(k, s);
+    case SHAPY_TILE_64x64: return launch_small<64, 64, 2, 2>(k, bk, s);
+    case SHAPY_TILE_128x48: return launch<128, 48, 4, 1>(k, s);
+    case SHAPY_TILE_128x64: return launch<128, 64, 4, 1>(k, s);
+    case SHAPY_TILE_256x96: return launch<256, 96, 4, 1>(k, s);
+    case SHAPY_TILE_256x128: return launch<256, 128, 2, 2>(k, s);
     default: return SHAPY_EINVAL;
   }
 }

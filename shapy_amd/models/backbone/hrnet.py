@@ -306,6 +306,7 @@ class HighResolutionNet(nn.Module):
         self._engine = {}
         self.multi_stream = True
         self.tile_overrides = {}
+        self.tile_flags = 0          # OR-ed into every conv's tile id (0x100 = XCD-contiguous)
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
 
     # ---- construction helpers (mirror hrnet.py:301-424) ----
@@ -429,7 +430,7 @@ class HighResolutionNet(nn.Module):
                  in_ld=inb.C, Ho=Ho, Wo=Wo, Cout=cout, ksize=ks, stride=st, pad=pad,
                  out_ld=out_ld or outb.C, out_coff=out_coff,
                  res_ld=(res_ld or (res.C if res is not None else 0)), res_coff=res_coff,
-                 relu=int(relu), ups=ups, tile=_lib.TILES[ov.get(name, 'auto')],
+                 relu=int(relu), ups=ups, tile=_lib.TILES[ov.get(name, 'auto')] | self.tile_flags,
                  wgt_off=P.add_weights(w), bias_off=P.add_weights(b))
             return outb, Ho, Wo
 
