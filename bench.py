@@ -40,6 +40,21 @@ def conv_flop_per_image(net, size):
     return 2 * macs
 
 
+def pmc_traffic(batch, size):
+    """HBM bytes per backbone forward from the committed rocprofv3 --pmc passes
+    (profiles/*_pmc_hbm_traffic.json; FETCH_SIZE and WRITE_SIZE need separate passes and cannot
+    be collected from inside this process).  None when the workload differs."""
+    import glob
+    for f in sorted(glob.glob(osp.join(ROOT, 'profiles', '*_pmc_hbm_traffic.json')), reverse=True):
+        with open(f) as fh:
+            d = json.load(fh)
+        h = d.get('hbm_bytes_per_backbone_forward', {})
+        if h.get('batch') == batch and h.get('size') == size:
+            return {'bytes_as_reported': h['as_reported'], 'bytes_fetch_x2_corrected':
+                    h['fetch_x2_corrected'], 'source': osp.relpath(f, ROOT)}
+    return None
+
+
 def cpu_baseline(batch, size, budget_s=15.0):
     """Times the CPU oracle (kind 'port') for about `budget_s` seconds of work."""
     import numpy as np
@@ -180,7 +195,7 @@ def main():
                        'multi_stream': not args.single_stream},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
-                         'traffic': None,
+                         'traffic': pmc_traffic(B, args.size),
                          'kernel': 'conv_igemm_f32_kernel (330 launches per backbone forward)',
                          'flop_per_launch_group': flop_img * B,
                          'ms_per_launch_group': backbone_ms},

@@ -55,10 +55,11 @@ POSE_ROTMAT, POSE_CONT6D, POSE_AXIS_ANGLE = 0, 1, 2
 TILES = {'auto': 0, '256x48': 1, '128x96': 2, '128x128': 3, '256x64': 4, '64x48': 5,
          '64x96': 6, '64x128': 7, '64x64': 8, '128x48': 9, '128x64': 10, '256x96': 11,
          '256x128': 12}
-for _k, _v in list(TILES.items()):      # tuning knobs: XCD-contiguous order, BK = 32
-    TILES[_k + '+swz'] = _v | 0x100
+for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: conv2d_f32)
+    TILES[_k + '+noswz'] = _v | 0x400
     TILES[_k + '+bk32'] = _v | 0x200
-    TILES[_k + '+swz+bk32'] = _v | 0x300
+    TILES[_k + '+bk16'] = _v | 0x800
+    TILES[_k + '+noswz+bk16'] = _v | 0xC00
 
 #: every symbol include/shapy_hip.h declares: (restype, argtypes)
 SIGNATURES = {

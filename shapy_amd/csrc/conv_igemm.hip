@@ -291,10 +291,15 @@ int conv2d_f32(const ShapyConv &d, hipStream_t s) {
   k.out_ld = d.out_ld; k.out_coff = d.out_coff; k.res_ld = d.res_ld; k.res_coff = d.res_coff;
   k.relu = d.relu; k.ups = d.ups;
   if (k.M <= 0 || k.Cout <= 0) return SHAPY_OK;
-  // d.tile: low byte = SHAPY_TILE_* (0 = auto), 0x100 = XCD-contiguous workgroup order,
-  // 0x200 = BK 32 (tuning knobs of tools/conv_bench.py)
-  k.swz = (d.tile & 0x100) ? 1 : 0;
-  const int bk = (d.tile & 0x200) ? 32 : 16;
+  // d.tile: low byte = SHAPY_TILE_* (0 = auto).  Tuning knobs of tools/conv_bench.py:
+  // 0x100 / 0x400 force the XCD-contiguous workgroup order on / off, 0x200 / 0x800 force
+  // BK = 32 / 16.  Defaults (profiles/conv_bench_r01*.txt): XCD-contiguous always (+2..7 %),
+  // BK 32 whenever the K loop is long enough to stay pipelined (+6..20 % on the 14x14 / 7x7
+  // layers, slower on K = 64).
+  k.swz = (d.tile & 0x400) ? 0 : 1;
+  int bk = (k.ks * k.ks * k.Cin >= 512 && (k.Cin & 31) == 0) ? 32 : 16;
+  if (d.tile & 0x200) bk = 32;
+  if (d.tile & 0x800) bk = 16;
   int tile = (d.tile & 0xff) ? (d.tile & 0xff) : conv_tile_auto(k.M, k.Cout);
   if (k.ups != 1 && tile != SHAPY_TILE_64x48 && tile != SHAPY_TILE_64x64)
     tile = (k.Cout % 64 == 0 && k.Cout % 48 != 0) ? SHAPY_TILE_64x64 : SHAPY_TILE_64x48;
