@@ -314,3 +314,38 @@ def test_measurements_large_batch_properties(network):
         one = bm.forward_vertices(v[i:i + 1], f).cpu().numpy()
         assert np.array_equal(one[0], out[i])
     assert abs(out[0, 2] - 0.8745367) < 2e-6      # mesh 0 is the shipped sample
+
+
+def test_mesh_to_mesh_bvh_path_bit_exact_vs_oracle():
+    """Large query meshes go through the LBVH (csrc/bvh.hip): same result as the brute-force
+    C oracle (and therefore as the scan path)."""
+    _need_gpu()
+    import mesh_mesh_intersect_cuda
+    from oracle import measure as om
+    from shapy_amd.utils import synthetic as syn
+    faces, meshes = syn.load_topology()
+    tris = np.ascontiguousarray(meshes[:, faces])                       # 4,F,3,3
+    target = np.ascontiguousarray(tris[[0, 1, 2]])
+    # query: 700 triangles of a *different* body (bodies overlap in space) + the plane quad
+    q = np.ascontiguousarray(np.concatenate(
+        [tris[[1, 2, 3]][:, 3000:3700], om.plane_triangles(np.array([-0.03, -0.25, -0.48], np.float32))],
+        axis=1))
+    mc = 320
+    f_ref, b_ref = om.mesh_to_mesh_forward(q, target, mc)
+    assert om.mesh_to_mesh_forward.last_dropped == 0
+    assert (f_ref >= 0).sum() > 500
+    f, b = mesh_mesh_intersect_cuda.mesh_to_mesh_forward(
+        torch.from_numpy(q).cuda(), torch.from_numpy(target).cuda(), max_collisions=mc)
+    torch.cuda.synchronize()
+    assert int(mesh_mesh_intersect_cuda.mesh_to_mesh_forward.last_overflow.item()) == 0
+    assert np.array_equal(f.cpu().numpy(), f_ref)
+    assert np.array_equal(b.cpu().numpy(), b_ref)
+    # self-intersection query (every triangle at least touches itself and its neighbours)
+    sub = np.ascontiguousarray(tris[:2, :1500])
+    f_ref, b_ref = om.mesh_to_mesh_forward(sub, sub, 64)
+    assert om.mesh_to_mesh_forward.last_dropped == 0
+    f, b = mesh_mesh_intersect_cuda.mesh_to_mesh_forward(
+        torch.from_numpy(sub).cuda(), torch.from_numpy(sub).cuda(), max_collisions=64)
+    torch.cuda.synchronize()
+    assert np.array_equal(f.cpu().numpy(), f_ref)
+    assert np.array_equal(b.cpu().numpy(), b_ref)
