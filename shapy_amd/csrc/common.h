@@ -8,6 +8,7 @@
 namespace shapy {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 enum {
   SHAPY_TILE_AUTO = 0,

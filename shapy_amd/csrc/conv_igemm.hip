@@ -22,6 +22,7 @@ struct ConvK {
   float *out;
   int M, Hi, Wi, Cin, in_ld, Ho, Wo, Cout, ks, stride, pad;
   int out_ld, out_coff, res_ld, res_coff, relu, ups, swz, nbx, nby;
+  unsigned in_bytes, wgt_bytes;
 };
 
 template <int BM, int BN, int WM, int WN, int UPS, int BK>
@@ -29,7 +30,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   static_assert(BK == 16 || BK == 32, "K chunk");
-  constexpr int LDS_LD = BK + 4;         // floats per staged row (+4 pad keeps b128 alignment)
+  // LDS rows are unpadded (BK floats); the 16-byte slot s of row r holds k-group
+  // s ^ f(r), f(r) = (r ^ (r >> 1)) & (KQ - 1): the ds_write_b128 of the staging pass and the
+  // ds_read_b128 of the fragment reads are then both bank-conflict free (exhaustively checked
+  // against the gfx950 lane-group table, tools/lds_swizzle_check.py)
+  constexpr int LDS_LD = BK;
   constexpr int KQ = BK / 4;             // float4 per staged row
   constexpr int RPP = 256 / KQ;          // rows staged per pass of the 256 threads
   constexpr int AR = BM / RPP;           // A rows staged per thread
@@ -50,7 +55,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
   const int m_blk = (wg / p.nbx) * BM, n_blk = (wg % p.nbx) * BN;
   const int kq = t % KQ, lrow = t / KQ;
 
-  // ---- per-thread staging addresses ----
+  // ---- per-thread staging addresses (byte offsets into buffer descriptors) ----
+  // Out-of-image taps and rows beyond M / Cout get an offset past num_records: the buffer
+  // load returns 0 for them, so zero padding costs one v_cndmask per load and no data select.
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, p.wgt_bytes, 0x00020000);
+  constexpr int OOB = 0x7fffffff;
   int a_off[AR], a_h[AR], a_w[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
@@ -61,61 +73,59 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
     const int ho = tq % p.Ho;
     const int b = tq / p.Ho;
     const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-    a_off[i] = ((b * p.Hi + hi0) * p.Wi + wi0) * p.in_ld + kq * 4;
+    a_off[i] = (((b * p.Hi + hi0) * p.Wi + wi0) * p.in_ld + kq * 4) * 4;
     a_h[i] = m < p.M ? hi0 : -0x40000000;
     a_w[i] = wi0;
   }
   const int Kw = p.ks * p.ks * p.Cin;
   int b_off[BR];
-  bool b_ok[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
     const int r = lrow + RPP * i;
     const int n = n_blk + r;
-    b_ok[i] = (r < BN) && (n < p.Cout);
-    b_off[i] = (b_ok[i] ? n : 0) * Kw + kq * 4;
+    b_off[i] = ((r < BN) && (n < p.Cout)) ? (n * Kw + kq * 4) * 4 : OOB;
   }
 
-  float4 a_reg[AR], b_reg[BR];
+  u32x4 a_reg[AR], b_reg[BR];
 
   // chunk iterator state for the NEXT chunk to be fetched
   int kh = 0, kw = 0, c0 = 0;
   const int n_chunks = p.ks * p.ks * (p.Cin / BK);
 
   auto gload = [&]() {
-    const int tap_in = (kh * p.Wi + kw) * p.in_ld + c0;
-    const int tap_w = (kh * p.ks + kw) * p.Cin + c0;
+    const int tap_in = ((kh * p.Wi + kw) * p.in_ld + c0) * 4;
+    const int tap_w = ((kh * p.ks + kw) * p.Cin + c0) * 4;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const bool ok = (unsigned)(a_h[i] + kh) < (unsigned)p.Hi &&
                       (unsigned)(a_w[i] + kw) < (unsigned)p.Wi;
-      // out-of-image taps read the tensor base (always valid memory) and are zeroed by a data
-      // select -- selecting between a global and a private address would force flat loads
-      const float4 v = *reinterpret_cast<const float4 *>(p.in + (ok ? a_off[i] + tap_in : kq * 4));
-      a_reg[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+      a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + tap_in : OOB, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const float4 v = *reinterpret_cast<const float4 *>(p.wgt + (b_off[i] + tap_w));
-      b_reg[i] = make_float4(b_ok[i] ? v.x : 0.f, b_ok[i] ? v.y : 0.f, b_ok[i] ? v.z : 0.f,
-                             b_ok[i] ? v.w : 0.f);
-    }
+    for (int i = 0; i < BR; ++i)
+      b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(
+          rs_w, b_off[i] == OOB ? OOB : b_off[i] + tap_w, 0, 0);
     c0 += BK;
     if (c0 == p.Cin) {
       c0 = 0;
       if (++kw == p.ks) { kw = 0; ++kh; }
     }
   };
+  // staging writes: row r, slot kq ^ f(r)
+  int st_off[AR > BR ? AR : BR];
+#pragma unroll
+  for (int i = 0; i < (AR > BR ? AR : BR); ++i) {
+    const int r = lrow + RPP * i;
+    st_off[i] = r * LDS_LD + ((kq ^ ((r ^ (r >> 1)) & (KQ - 1))) << 2);
+  }
   auto lstore = [&](int buf) {
     float *A = lds[buf];
     float *Bt = lds[buf] + BM * LDS_LD;
 #pragma unroll
-    for (int i = 0; i < AR; ++i)
-      *reinterpret_cast<float4 *>(A + (lrow + RPP * i) * LDS_LD + kq * 4) = a_reg[i];
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<u32x4 *>(A + st_off[i]) = a_reg[i];
 #pragma unroll
     for (int i = 0; i < BR; ++i)
-      if (lrow + RPP * i < BN)
-        *reinterpret_cast<float4 *>(Bt + (lrow + RPP * i) * LDS_LD + kq * 4) = b_reg[i];
+      if (lrow + RPP * i < BN) *reinterpret_cast<u32x4 *>(Bt + st_off[i]) = b_reg[i];
   };
 
   f32x4 acc[TM][TN];
@@ -124,9 +134,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int frag_off = (lane & 15) * LDS_LD + (lane >> 4) * 4;
-  const int a_base = wm * (BM / WM) * LDS_LD + frag_off;
-  const int b_base = BM * LDS_LD + wn * (BN / WN) * LDS_LD + frag_off;
+  // fragment reads: row (lane & 15) of a 16-row tile, k-group (lane >> 4) + 4 * sub
+  const int fr = ((lane & 15) ^ ((lane & 15) >> 1)) & (KQ - 1);
+  int frag_off[BK / 16];
+#pragma unroll
+  for (int sub = 0; sub < BK / 16; ++sub)
+    frag_off[sub] = (lane & 15) * LDS_LD + ((((lane >> 4) + 4 * sub) ^ fr) << 2);
+  const int a_base = wm * (BM / WM) * LDS_LD;
+  const int b_base = BM * LDS_LD + wn * (BN / WN) * LDS_LD;
 
   gload();
   lstore(0);
@@ -142,10 +157,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
       f32x4 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const f32x4 *>(L + a_base + i * 16 * LDS_LD + sub * 16);
+        af[i] = *reinterpret_cast<const f32x4 *>(L + a_base + i * 16 * LDS_LD + frag_off[sub]);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const f32x4 *>(L + b_base + j * 16 * LDS_LD + sub * 16);
+        bf[j] = *reinterpret_cast<const f32x4 *>(L + b_base + j * 16 * LDS_LD + frag_off[sub]);
       // k-step outermost: consecutive MFMAs hit different accumulators (the 16x16x4 f32 MFMA
       // has a 40-cycle dependent latency vs a 32-cycle issue interval)
 #pragma unroll
@@ -290,6 +305,10 @@ int conv2d_f32(const ShapyConv &d, hipStream_t s) {
   k.Cout = d.Cout; k.ks = d.ksize; k.stride = d.stride; k.pad = d.pad;
   k.out_ld = d.out_ld; k.out_coff = d.out_coff; k.res_ld = d.res_ld; k.res_coff = d.res_coff;
   k.relu = d.relu; k.ups = d.ups;
+  const unsigned long long in_bytes = 4ull * d.B * d.Hi * d.Wi * d.in_ld;
+  const unsigned long long wgt_bytes = 4ull * d.Cout * d.ksize * d.ksize * d.Cin;
+  if (in_bytes >= 0x7fffffffull || wgt_bytes >= 0x7fffffffull) return SHAPY_EINVAL;   // 32-bit offsets
+  k.in_bytes = (unsigned)in_bytes; k.wgt_bytes = (unsigned)wgt_bytes;
   if (k.M <= 0 || k.Cout <= 0) return SHAPY_OK;
   // d.tile: low byte = SHAPY_TILE_* (0 = auto).  Tuning knobs of tools/conv_bench.py:
   // 0x100 / 0x400 force the XCD-contiguous workgroup order on / off, 0x200 / 0x800 force

@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--tiles', default='auto')
     ap.add_argument('--iters', type=int, default=8)
     ap.add_argument('--out', default='')
+    ap.add_argument('--filter', default='', help='Hi,Cin,Cout,ksize: run only this class')
     args = ap.parse_args()
     lib = _lib.load()
     net = HighResolutionNet(default_config().network.smplx.backbone.hrnet)
@@ -43,8 +44,11 @@ def main():
     B = args.batch
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     rows = []
+    flt = [int(v) for v in args.filter.split(',')] if args.filter else None
     for key, count in classes.items():
         Hi, Wi, Cin, Cout, ks, st, ups, has_res, relu = key
+        if flt and [Hi, Cin, Cout, ks] != flt:
+            continue
         pad = ks // 2
         Ho, Wo = (Hi + 2 * pad - ks) // st + 1, (Wi + 2 * pad - ks) // st + 1
         x = torch.randn(B, Hi, Wi, Cin, device='cuda')
@@ -85,6 +89,8 @@ def main():
     print('# Hi Cin->Cout k s ups res | count | M | tile: us (TFLOP/s) ... | share of total')
     for key in classes:
         rs = [r for r in rows if r['key'] == key]
+        if not rs:
+            continue
         Hi, Wi, Cin, Cout, ks, st, ups, has_res, relu = key
         s = ' '.join(f"{r['tile']}:{r['us']:.0f}us({r['tflops']:.0f})" for r in rs)
         bb = best[key]
