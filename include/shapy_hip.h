@@ -205,6 +205,19 @@ int shapy_body_measure_f32(const float *v_shaped, const int32_t *faces, int B, i
                            float *out, void *workspace, size_t workspace_bytes,
                            int32_t *overflow_out, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Input pre-processing (the step in front of the hot path): crop window -> bilinear resize
+ * to S x S -> clamp -> normalise, for a ragged batch of full HWC uint8 images.
+ *   images: concatenated uint8 RGB images; img_off[b]: byte offset of image b; img_hw[b] = (H, W)
+ *   boxes[b] = (ul_x, ul_y, br_x, br_y): integer crop window in full-image pixels, computed like
+ *   transf_utils.transform (regressor/human_shape/utils/transf_utils.py:40-66); pixels of the
+ *   window outside the image are zero.   out: [B,3,S,S] float32 = (clamp(x,0,1) - mean) / std.
+ * ------------------------------------------------------------------------------------- */
+int shapy_crop_resize_normalize_u8(const unsigned char *images, const int64_t *img_off,
+                                   const int32_t *img_hw, const int32_t *boxes, float *out, int B,
+                                   int S, const float *mean_host, const float *std_host,
+                                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,7 @@ SOURCES = {
     # bit-identical float32 decisions with the CPU oracle: no FMA contraction here
     'measure.hip': ['-ffp-contract=off'],
     'bvh.hip': ['-ffp-contract=off'],
+    'preprocess.hip': ['-ffp-contract=off'],
     'capi.hip': [],
 }
 COMMON = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
