@@ -205,6 +205,12 @@ int shapy_body_measure_f32(const float *v_shaped, const int32_t *faces, int B, i
                            float *out, void *workspace, size_t workspace_bytes,
                            int32_t *overflow_out, void *stream);
 
+/* B2A attribute head: degree-2 polynomial of the betas followed by a Linear layer
+ * (attributes/attributes/attributes_betas/polynomial.py:61-69,137-140).
+ * betas [B,NB], weight [NA, NB + NB(NB+1)/2], bias [NA] -> out [B,NA]. */
+int shapy_b2a_polynomial_f32(const float *betas, const float *weight, const float *bias,
+                             float *out, int B, int NB, int NA, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Input pre-processing (the step in front of the hot path): crop window -> bilinear resize
  * to S x S -> clamp -> normalise, for a ragged batch of full HWC uint8 images.

@@ -83,6 +83,8 @@ SIGNATURES = {
                                             ctypes.c_int, vp]),
     'shapy_smplx_joints_f32': (ctypes.c_int, [ctypes.POINTER(ShapySmplxModel), vp, vp, vp, vp, vp,
                                               vp, vp, ctypes.c_int, ctypes.c_int, vp]),
+    'shapy_b2a_polynomial_f32': (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, vp]),
     'shapy_crop_resize_normalize_u8': (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int,
                                                       c_float_p, c_float_p, vp]),
     'shapy_mesh_to_mesh_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 4),

@@ -353,6 +353,27 @@ __global__ __launch_bounds__(256) void joint_regress_kernel(const float *__restr
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+
+// B2A: degree-2 polynomial features of the betas -> Linear (attributes/attributes/
+// attributes_betas/polynomial.py:61-69,137-140).  Monomial order = itertools
+// combinations_with_replacement(range(NB), 1) ++ (..., 2): x_0..x_{NB-1}, x_0x_0, x_0x_1, ...
+__global__ void b2a_polynomial_kernel(const float *__restrict__ betas, const float *__restrict__ W,
+                                      const float *__restrict__ bias, float *__restrict__ out,
+                                      int NB, int NA, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int a = (int)(i % NA);
+  const long b = i / NA;
+  const float *x = betas + b * NB;
+  const float *w = W + (long)a * (NB + NB * (NB + 1) / 2);
+  float s = bias[a];
+  int m = 0;
+  for (int p = 0; p < NB; ++p) s = fmaf(w[m++], x[p], s);
+  for (int p = 0; p < NB; ++p)
+    for (int q = p; q < NB; ++q) s = fmaf(w[m++], x[p] * x[q], s);
+  out[i] = s;
+}
+
 }  // namespace shapy
 
 using namespace shapy;
@@ -436,5 +457,14 @@ extern "C" int shapy_joint_regress_f32(const float *regressor, const float *vert
   if (B <= 0 || Jn <= 0) return SHAPY_OK;
   hipLaunchKernelGGL(joint_regress_kernel, dim3(Jn, B), dim3(256), 0, (hipStream_t)stream, regressor,
                      vertices, out, V, Jn);
+  return (int)hipGetLastError();
+}
+
+extern "C" int shapy_b2a_polynomial_f32(const float *betas, const float *weight, const float *bias,
+                                        float *out, int B, int NB, int NA, void *stream) {
+  const long total = (long)B * NA;
+  if (total <= 0) return SHAPY_OK;
+  hipLaunchKernelGGL(b2a_polynomial_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, betas, weight, bias, out, NB, NA, total);
   return (int)hipGetLastError();
 }

@@ -82,16 +82,23 @@ class HMRLikeRegressor(nn.Module):
                  'meas_vertices_path': meas_vertices_path})
 
         use_b2a = network_cfg.get('use_b2a', False)
-        self.use_b2a = bool(use_b2a and osp.exists(expand(network_cfg.get('b2a_males_checkpoint', '')))
-                            and osp.exists(expand(network_cfg.get('b2a_females_checkpoint', ''))))
+        b2a_m = expand(network_cfg.get('b2a_males_checkpoint', ''))
+        b2a_f = expand(network_cfg.get('b2a_females_checkpoint', ''))
+        self.use_b2a = bool(use_b2a and osp.exists(b2a_m) and osp.exists(b2a_f))
+        if self.use_b2a:                                   # iterative_regressor.py:146-172
+            from ..attributes import B2A
+            self.b2a_males = B2A.load_from_checkpoint(b2a_m)
+            self.b2a_females = B2A.load_from_checkpoint(b2a_f)
+            for p in list(self.b2a_males.parameters()) + list(self.b2a_females.parameters()):
+                p.requires_grad = False
         use_a2b = network_cfg.get('use_a2b', False)
         self.num_attributes = network_cfg.get('num_attributes', False)
         self.use_a2b = bool(use_a2b and osp.exists(expand(network_cfg.get('a2b_males_checkpoint', '')))
                             and osp.exists(expand(network_cfg.get('a2b_females_checkpoint', ''))))
-        if self.use_b2a or self.use_a2b:
+        if self.use_a2b:
             raise NotImplementedError(
-                'B2A / A2B attribute heads need pytorch_lightning checkpoints; they are a '
-                '"next" row (SURVEY.md 8f n3), not part of the measured hot path')
+                'the A2B refinement head (normalising flows / MLP Lightning modules) is a separate '
+                'demo of the reference, not part of the image->shape hot path (SURVEY.md section 2)')
         self._faces_i32 = {}
 
     # ---- reference properties ----
@@ -228,6 +235,20 @@ class HMRLikeRegressor(nn.Module):
 
         out_params['stage_keys'] = stage_keys
         out_params[stage_keys[-1]]['proj_joints'] = proj_joints
+
+        if self.use_b2a:                                   # iterative_regressor.py:761-776
+            genders = [x.get_field('gender') if x.has_field('gender') else None
+                       for x in targets] if targets else [None] * batch_size
+            genders = np.array([g.lower()[0] if (g is not None and g != '') else 'n'
+                                for g in genders])
+            betas = parameters[-1][:, self._slices['betas'][0]:self._slices['betas'][1]]
+            attributes = torch.zeros(betas.shape[0], self.b2a_males.b2a.output_dim,
+                                     device=betas.device)
+            for g, module in (('m', self.b2a_males), ('f', self.b2a_females)):
+                idx = torch.from_numpy(np.where(genders == g)[0]).to(betas.device)
+                if len(idx):
+                    attributes[idx] = module(betas[idx])
+            out_params['attributes'] = attributes
         if self.training and compute_losses:
             raise NotImplementedError('training losses are out of scope (SURVEY.md section 2)')
         out_params['losses'] = {}
