@@ -31,10 +31,11 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 CONV_FLOP_PER_IMAGE_224 = 2 * 18_466_524_160       # SURVEY.md 8(d), counted from the reference
 F32_MFMA_PEAK_TFLOPS = 157.3                       # MI355X_MICROARCH.md, dense f32 MFMA
+BF16_MFMA_PEAK_TFLOPS = 2500.0                     # dense bf16 MFMA (not the 2:1-sparse figure)
 
 
 def conv_flop_per_image(net, size):
-    plan = net.backbone._build_plan(size, size)
+    plan = net.backbone._build_plan(size, size)      # f32 plan: algorithmic (unpadded) MACs
     macs = sum(o['Ho'] * o['Wo'] * o['Cout'] * o['Cin'] * o['ksize'] ** 2
                for o in plan.ops if o['type'] != 2)
     return 2 * macs
@@ -108,6 +109,8 @@ def main():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--single-stream', action='store_true')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help='f32 = BASELINE configs[1] (headline); bf16 = configs[2] storage type')
     args = ap.parse_args()
 
     import numpy as np
@@ -131,6 +134,7 @@ def main():
     net, _ = ge.make_network(model_folder=f'/tmp/shapy_synth_models_r{local_rank}' if world > 1
                              else '/tmp/shapy_synth_models')
     net.backbone.multi_stream = not args.single_stream
+    net.backbone.compute_dtype = args.dtype
     B = args.batch
     # distinct synthetic images per rank (global batch = world * B), resident in HBM
     x = torch.from_numpy(syn.synthetic_images(B, args.size, 100 + rank)).cuda()
@@ -174,6 +178,7 @@ def main():
     backbone_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     flop_img = conv_flop_per_image(net, args.size)
     achieved = flop_img * B / (backbone_ms * 1e-3) / 1e12
+    peak = F32_MFMA_PEAK_TFLOPS if args.dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
     if rank == 0:
         res = {
             'metric': 'images/sec whole-node (HRNet+SMPL-X fwd), 224x224 bs=64; betas L2 vs CPU',
@@ -186,21 +191,23 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': args.dtype,
             'data': 'synthetic',
             'config': {'workload': f'HRNet-W48 + iterative regressor + SMPL-X + virtual '
                                    f'measurements, random-init weights, {args.size}x{args.size}, '
-                                   f'bs={B} per GPU, fp32 (BASELINE configs[1])',
+                                   f'bs={B} per GPU, ' + ('fp32 (BASELINE configs[1])' if args.dtype == 'f32'
+                                                          else 'bf16 storage / f32 accumulate '
+                                                               '(BASELINE configs[2] precision)'),
                        'global_batch': world * B, 'parallelism': f'dp{world}',
                        'multi_stream': not args.single_stream},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
-                         'traffic': pmc_traffic(B, args.size),
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak,
+                         'unit': 'TFLOP/s', 'frac': achieved / peak,
+                         'traffic': pmc_traffic(B, args.size) if args.dtype == 'f32' else None,
                          'kernel': 'conv_igemm_f32_kernel (330 launches per backbone forward)',
                          'flop_per_launch_group': flop_img * B,
                          'ms_per_launch_group': backbone_ms},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             res['cpu_baseline'] = cpu_baseline(B, args.size)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -7,7 +7,7 @@
  *
  * What each entry point replaces in the reference (muelea/shapy):
  *
- *  shapy_conv2d_f32 / shapy_hrnet_run_f32
+ *  shapy_conv2d / shapy_hrnet_run
  *      the 331 cuDNN convolutions + eval-mode BatchNorm + ReLU + residual adds + nearest
  *      upsampling + concat + spatial mean of HighResolutionNet.forward
  *      (regressor/human_shape/models/backbone/hrnet.py:426-498, :175-193)
@@ -57,15 +57,17 @@ const char *shapy_build_arch(void);
  * conv1x1 + BN + nearest-Upsample + add of an HRNet fuse layer (hrnet.py:125-136,184-191) in
  * one pass.  BatchNorm is folded into wgt/bias by the host (float64).
  * A plain GEMM out[M,N] = in[M,K] * wgt[N,K]^T + bias is the case ksize=1, Hi=Wi=Ho=Wo=1,
- * B=M.  Requirements: Cin % 16 == 0, all pointers 16-byte aligned, in_ld/out_ld/res_ld % 4 == 0
- * is NOT required (only Cin and in_ld % 4 == 0).
+ * B=M.  Requirements: Cin % 16 == 0 (f32) / % 32 == 0 (bf16), in and wgt 16-byte aligned,
+ * in_ld a multiple of 16 bytes; tensors smaller than 2 GiB (32-bit buffer offsets).
  * ------------------------------------------------------------------------------------- */
+enum { SHAPY_DTYPE_F32 = 0, SHAPY_DTYPE_BF16 = 1 };
+
 typedef struct ShapyConv {
-  const float *in;    /* [B, Hi, Wi, in_ld]   (first Cin channels of each pixel are used)   */
-  const float *wgt;   /* [Cout, ksize, ksize, Cin]                                         */
-  const float *bias;  /* [Cout] or NULL                                                    */
-  const float *res;   /* residual, indexed like out (res_ld, res_coff), or NULL; may == out */
-  float *out;         /* [B, Ho*ups, Wo*ups, out_ld]                                       */
+  const void *in;     /* [B, Hi, Wi, in_ld]   (first Cin channels of each pixel are used)   */
+  const void *wgt;    /* [Cout, ksize, ksize, Cin]                                         */
+  const float *bias;  /* [Cout] float32 or NULL                                            */
+  const void *res;    /* residual, indexed like out (res_ld, res_coff), or NULL; may == out */
+  void *out;          /* [B, Ho*ups, Wo*ups, out_ld]                                       */
   int32_t B, Hi, Wi, Cin, in_ld;
   int32_t Ho, Wo, Cout;
   int32_t ksize, stride, pad;
@@ -73,9 +75,11 @@ typedef struct ShapyConv {
   int32_t relu;       /* 1: ReLU after the (residual) add                                  */
   int32_t ups;        /* 1 = none; 2/4/8 = nearest-upsample scatter                        */
   int32_t tile;       /* 0 = choose automatically; else a SHAPY_TILE_* id (bench/tuning)   */
+  int32_t dtype;      /* storage type of in / wgt / res / out: SHAPY_DTYPE_F32 (f32 MFMA, exact
+                         f32) or SHAPY_DTYPE_BF16 (bf16 MFMA, f32 accumulate; Cin % 32 == 0)  */
 } ShapyConv;
 
-int shapy_conv2d_f32(const ShapyConv *desc_host, void *stream);
+int shapy_conv2d(const ShapyConv *desc_host, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * HRNet op list.  The host (Python) flattens the module tree into `ops`; buffers are
@@ -97,10 +101,14 @@ typedef struct ShapyOp {
 
 /* input: [B,3,H,W] NCHW f32 (the reference's layout, iterative_regressor.py:623);
  * features_out: [B, Cfeat].  workspace must hold B * ws_floats_per_image floats. */
-int shapy_hrnet_run_f32(const ShapyOp *ops_host, int n_ops, const float *weights,
-                        const float *input_nchw, float *workspace, int64_t ws_floats_per_image,
-                        float *features_out, int B, int H, int W, int multi_stream,
-                        void *stream);
+int shapy_hrnet_run(const ShapyOp *ops_host, int n_ops, const void *weights,
+                    const float *input_nchw, void *workspace, int64_t ws_elems_per_image,
+                    float *features_out, int B, int H, int W, int multi_stream, int dtype,
+                    void *stream);
+/* dtype = SHAPY_DTYPE_F32: weights / workspace are float32 (the parity path);
+ * SHAPY_DTYPE_BF16: conv weights and activations are bfloat16 (biases stay float32 and live in
+ * the blob at 4-byte granularity: bias_off counts float32 elements, wgt_off bfloat16 elements),
+ * the network input and the features stay float32 (BASELINE configs[2]). */
 
 /* ---------------------------------------------------------------------------------------
  * Iterative regressor, affine-collapsed form.  The SHAPY_A MLP has no activation and no

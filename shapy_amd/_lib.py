@@ -28,7 +28,7 @@ class ShapyConv(ctypes.Structure):
                 ('Ho', i32), ('Wo', i32), ('Cout', i32),
                 ('ksize', i32), ('stride', i32), ('pad', i32),
                 ('out_ld', i32), ('out_coff', i32), ('res_ld', i32), ('res_coff', i32),
-                ('relu', i32), ('ups', i32), ('tile', i32)]
+                ('relu', i32), ('ups', i32), ('tile', i32), ('dtype', i32)]
 
 
 class ShapyOp(ctypes.Structure):
@@ -52,10 +52,10 @@ class ShapySmplxModel(ctypes.Structure):
 
 OP_CONV, OP_STEM, OP_MEANPOOL = 0, 1, 2
 POSE_ROTMAT, POSE_CONT6D, POSE_AXIS_ANGLE = 0, 1, 2
+DTYPE_F32, DTYPE_BF16 = 0, 1
 TILES = {'auto': 0, '256x48': 1, '128x96': 2, '128x128': 3, '256x64': 4, '64x48': 5,
-         '64x96': 6, '64x128': 7, '64x64': 8, '128x48': 9, '128x64': 10, '256x96': 11,
-         '256x128': 12}
-for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: conv2d_f32)
+         '64x96': 6, '64x128': 7, '64x64': 8, '128x48': 9, '128x64': 10}
+for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: conv2d)
     TILES[_k + '+noswz'] = _v | 0x400
     TILES[_k + '+bk32'] = _v | 0x200
     TILES[_k + '+bk16'] = _v | 0x800
@@ -65,10 +65,10 @@ for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: con
 SIGNATURES = {
     'shapy_abi_version': (ctypes.c_int, []),
     'shapy_build_arch': (ctypes.c_char_p, []),
-    'shapy_conv2d_f32': (ctypes.c_int, [ctypes.POINTER(ShapyConv), vp]),
-    'shapy_hrnet_run_f32': (ctypes.c_int, [ctypes.POINTER(ShapyOp), ctypes.c_int, vp, vp, vp, i64,
-                                           vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                           ctypes.c_int, vp]),
+    'shapy_conv2d': (ctypes.c_int, [ctypes.POINTER(ShapyConv), vp]),
+    'shapy_hrnet_run': (ctypes.c_int, [ctypes.POINTER(ShapyOp), ctypes.c_int, vp, vp, vp, i64, vp,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, vp]),
     'shapy_regressor_affine_f32': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, vp]),

@@ -22,11 +22,9 @@ enum {
   SHAPY_TILE_64x64 = 8,
   SHAPY_TILE_128x48 = 9,
   SHAPY_TILE_128x64 = 10,
-  SHAPY_TILE_256x96 = 11,
-  SHAPY_TILE_256x128 = 12,
 };
 
-int conv2d_f32(const ShapyConv &d, hipStream_t s);
+int conv2d(const ShapyConv &d, hipStream_t s);
 int conv_tile_auto(int M, int Cout);
 
 inline int hip_rc(hipError_t e) { return (int)e; }

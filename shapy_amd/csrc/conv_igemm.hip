@@ -1,4 +1,5 @@
-// Implicit-GEMM convolution on the CDNA4 f32 matrix cores (v_mfma_f32_16x16x4_f32).
+// Implicit-GEMM convolution on the CDNA4 matrix cores: float32 (v_mfma_f32_16x16x4_f32, exact
+// f32) and bfloat16 storage with f32 accumulation (v_mfma_f32_16x16x32_bf16).
 //
 // Replaces every cuDNN conv + eval BatchNorm + ReLU + residual add + nearest upsample of the
 // reference's HighResolutionNet.forward (regressor/human_shape/models/backbone/hrnet.py:426-498)
@@ -6,40 +7,68 @@
 //
 // GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = ks*ks*Cin, NHWC activations,
 // OHWI weights (K contiguous for both operands).  One 256-thread workgroup (4 waves) owns a
-// BM x BN tile; K is consumed in 16-float chunks staged through double-buffered LDS:
-// global -> VGPR (float4, issued before the MFMAs of the current chunk) -> LDS -> b128
-// fragment reads.  Lane l of a wave reads 4 consecutive k of row (l&15) starting at
-// 4*(l>>4) with ONE ds_read_b128 and feeds them to 4 successive MFMAs; A and B use the same
-// k permutation so the sum over k is unchanged.  f32 MFMA is exact f32 (an fmaf chain), so
-// parity with the CPU reference is at rounding level.
+// BM x BN tile; K is consumed in chunks of KQ 16-byte slots per row staged through
+// double-buffered LDS: buffer_load_dwordx4 (issued before the MFMAs of the current chunk;
+// out-of-image taps are zeroed by the hardware bounds check) -> ds_write_b128 -> one barrier
+// per chunk -> ds_read_b128 fragment reads.
+//   f32 : a 16-byte slot = 4 consecutive k.  Lane l reads slot (l >> 4) of row (l & 15) and
+//         feeds its 4 floats to 4 successive 16x16x4 MFMAs; A and B use the same k permutation,
+//         so the sum over k is unchanged and the result is the exact-f32 fmaf chain.
+//   bf16: a slot = 8 consecutive k = exactly the per-lane operand of one 16x16x32 MFMA.
+// LDS rows are unpadded; slot s of row r holds k-group s ^ f(r), f(r) = (r ^ (r >> 1)) & (KQ-1),
+// which makes both the staging writes and the fragment reads bank-conflict free
+// (tools/lds_swizzle_check.py checks the gfx950 lane-group table exhaustively).
 #include "common.h"
 
 namespace shapy {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct F32 {
+  using elem = float;
+  static constexpr int EPS = 4;       // elements per 16-byte slot
+  static __device__ __forceinline__ float load(const void *p, long i) {
+    return reinterpret_cast<const float *>(p)[i];
+  }
+  static __device__ __forceinline__ void store(void *p, long i, float v) {
+    reinterpret_cast<float *>(p)[i] = v;
+  }
+};
+
+struct BF16 {
+  using elem = unsigned short;
+  static constexpr int EPS = 8;
+  static __device__ __forceinline__ float load(const void *p, long i) {
+    return __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(p)[i] << 16);
+  }
+  static __device__ __forceinline__ void store(void *p, long i, float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);                    // round to nearest even
+    reinterpret_cast<unsigned short *>(p)[i] = (unsigned short)(u >> 16);
+  }
+};
 
 struct ConvK {
-  const float *in, *wgt, *bias, *res;
-  float *out;
+  const void *in, *wgt, *res;
+  const float *bias;
+  void *out;
   int M, Hi, Wi, Cin, in_ld, Ho, Wo, Cout, ks, stride, pad;
   int out_ld, out_coff, res_ld, res_coff, relu, ups, swz, nbx, nby;
   unsigned in_bytes, wgt_bytes;
 };
 
-template <int BM, int BN, int WM, int WN, int UPS, int BK>
-__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
+template <typename T, int BM, int BN, int WM, int WN, int UPS, int KQ>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(KQ == 4 || KQ == 8, "16-byte slots per staged row");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  static_assert(BK == 16 || BK == 32, "K chunk");
-  // LDS rows are unpadded (BK floats); the 16-byte slot s of row r holds k-group
-  // s ^ f(r), f(r) = (r ^ (r >> 1)) & (KQ - 1): the ds_write_b128 of the staging pass and the
-  // ds_read_b128 of the fragment reads are then both bank-conflict free (exhaustively checked
-  // against the gfx950 lane-group table, tools/lds_swizzle_check.py)
-  constexpr int LDS_LD = BK;
-  constexpr int KQ = BK / 4;             // float4 per staged row
-  constexpr int RPP = 256 / KQ;          // rows staged per pass of the 256 threads
-  constexpr int AR = BM / RPP;           // A rows staged per thread
+  constexpr int ESZ = sizeof(typename T::elem);
+  constexpr int BK = KQ * T::EPS;            // K elements per chunk
+  constexpr int ROWB = KQ * 16;              // bytes per staged row
+  constexpr int RPP = 256 / KQ;              // rows staged per pass of the 256 threads
+  constexpr int AR = BM / RPP;               // A rows staged per thread
   constexpr int BR = (BN + RPP - 1) / RPP;   // B rows staged per thread (guarded)
-  __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_LD];
+  __shared__ __attribute__((aligned(16))) char lds[2][(BM + BN) * ROWB];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -59,9 +88,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
   // Out-of-image taps and rows beyond M / Cout get an offset past num_records: the buffer
   // load returns 0 for them, so zero padding costs one v_cndmask per load and no data select.
   const __amdgpu_buffer_rsrc_t rs_in =
-      __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, p.in_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w =
-      __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, p.wgt_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt), 0, p.wgt_bytes, 0x00020000);
   constexpr int OOB = 0x7fffffff;
   int a_off[AR], a_h[AR], a_w[AR];
 #pragma unroll
@@ -73,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
     const int ho = tq % p.Ho;
     const int b = tq / p.Ho;
     const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-    a_off[i] = (((b * p.Hi + hi0) * p.Wi + wi0) * p.in_ld + kq * 4) * 4;
+    a_off[i] = ((b * p.Hi + hi0) * p.Wi + wi0) * p.in_ld * ESZ + kq * 16;
     a_h[i] = m < p.M ? hi0 : -0x40000000;
     a_w[i] = wi0;
   }
@@ -83,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
   for (int i = 0; i < BR; ++i) {
     const int r = lrow + RPP * i;
     const int n = n_blk + r;
-    b_off[i] = ((r < BN) && (n < p.Cout)) ? (n * Kw + kq * 4) * 4 : OOB;
+    b_off[i] = ((r < BN) && (n < p.Cout)) ? n * Kw * ESZ + kq * 16 : OOB;
   }
 
   u32x4 a_reg[AR], b_reg[BR];
@@ -93,8 +122,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
   const int n_chunks = p.ks * p.ks * (p.Cin / BK);
 
   auto gload = [&]() {
-    const int tap_in = ((kh * p.Wi + kw) * p.in_ld + c0) * 4;
-    const int tap_w = ((kh * p.ks + kw) * p.Cin + c0) * 4;
+    const int tap_in = ((kh * p.Wi + kw) * p.in_ld + c0) * ESZ;
+    const int tap_w = ((kh * p.ks + kw) * p.Cin + c0) * ESZ;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const bool ok = (unsigned)(a_h[i] + kh) < (unsigned)p.Hi &&
@@ -116,11 +145,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
 #pragma unroll
   for (int i = 0; i < (AR > BR ? AR : BR); ++i) {
     const int r = lrow + RPP * i;
-    st_off[i] = r * LDS_LD + ((kq ^ ((r ^ (r >> 1)) & (KQ - 1))) << 2);
+    st_off[i] = r * ROWB + ((kq ^ ((r ^ (r >> 1)) & (KQ - 1))) << 4);
   }
   auto lstore = [&](int buf) {
-    float *A = lds[buf];
-    float *Bt = lds[buf] + BM * LDS_LD;
+    char *A = lds[buf];
+    char *Bt = lds[buf] + BM * ROWB;
 #pragma unroll
     for (int i = 0; i < AR; ++i) *reinterpret_cast<u32x4 *>(A + st_off[i]) = a_reg[i];
 #pragma unroll
@@ -134,14 +163,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment reads: row (lane & 15) of a 16-row tile, k-group (lane >> 4) + 4 * sub
+  // fragment reads: row (lane & 15) of a 16-row tile, slot (lane >> 4) + 4 * sub
   const int fr = ((lane & 15) ^ ((lane & 15) >> 1)) & (KQ - 1);
-  int frag_off[BK / 16];
+  int frag_off[KQ / 4];
 #pragma unroll
-  for (int sub = 0; sub < BK / 16; ++sub)
-    frag_off[sub] = (lane & 15) * LDS_LD + ((((lane >> 4) + 4 * sub) ^ fr) << 2);
-  const int a_base = wm * (BM / WM) * LDS_LD;
-  const int b_base = BM * LDS_LD + wn * (BN / WN) * LDS_LD;
+  for (int sub = 0; sub < KQ / 4; ++sub)
+    frag_off[sub] = (lane & 15) * ROWB + ((((lane >> 4) + 4 * sub) ^ fr) << 4);
+  const int a_base = wm * (BM / WM) * ROWB;
+  const int b_base = BM * ROWB + wn * (BN / WN) * ROWB;
 
   gload();
   lstore(0);
@@ -151,25 +180,36 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
     const int cur = kc & 1;
     const bool more = kc + 1 < n_chunks;
     if (more) gload();
-    const float *L = lds[cur];
+    const char *L = lds[cur];
 #pragma unroll
-    for (int sub = 0; sub < BK / 16; ++sub) {
-      f32x4 af[TM], bf[TN];
+    for (int sub = 0; sub < KQ / 4; ++sub) {
+      u32x4 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const f32x4 *>(L + a_base + i * 16 * LDS_LD + frag_off[sub]);
+        af[i] = *reinterpret_cast<const u32x4 *>(L + a_base + i * 16 * ROWB + frag_off[sub]);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const f32x4 *>(L + b_base + j * 16 * LDS_LD + frag_off[sub]);
-      // k-step outermost: consecutive MFMAs hit different accumulators (the 16x16x4 f32 MFMA
-      // has a 40-cycle dependent latency vs a 32-cycle issue interval)
+        bf[j] = *reinterpret_cast<const u32x4 *>(L + b_base + j * 16 * ROWB + frag_off[sub]);
+      if constexpr (sizeof(typename T::elem) == 4) {
+        // k-step outermost: consecutive MFMAs hit different accumulators (the 16x16x4 f32 MFMA
+        // has a 40-cycle dependent latency vs a 32-cycle issue interval)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                  __uint_as_float(af[i][kk]), __uint_as_float(bf[j][kk]), acc[i][j], 0, 0, 0);
+      } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0,
+                0, 0);
+      }
     }
     if (more) lstore(cur ^ 1);
     __syncthreads();
@@ -202,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
           for (int r = 0; r < 4; ++r) {
             const int row = row0 + i * 16 + r;
             if (col < p.Cout && row < p.M)
-              acc[i][j][r] += p.res[(long)row * p.res_ld + p.res_coff + col];
+              acc[i][j][r] += T::load(p.res, (long)row * p.res_ld + p.res_coff + col);
           }
       }
     }
@@ -216,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
           const int row = row0 + i * 16 + r;
           if (col < p.Cout && row < p.M) {
             const float o = p.relu ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
-            p.out[(long)row * p.out_ld + p.out_coff + col] = o;
+            T::store(p.out, (long)row * p.out_ld + p.out_coff + col, o);
           }
         }
     }
@@ -241,18 +281,20 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
           const int col = col0 + j * 16;
           if (col >= p.Cout) continue;
           const float v = acc[i][j][r];
-          const float *rp = p.res ? p.res + pix0 * p.res_ld + p.res_coff + col : nullptr;
-          float *op = p.out + pix0 * p.out_ld + p.out_coff + col;
+          const long rbase = pix0 * p.res_ld + p.res_coff + col;
+          const long obase = pix0 * p.out_ld + p.out_coff + col;
 #pragma unroll
           for (int dy0 = 0; dy0 < UPS; dy0 += RG) {
             float tmp[RG * UPS];
 #pragma unroll
             for (int q = 0; q < RG * UPS; ++q)
-              tmp[q] = rp ? rp[((long)(dy0 + q / UPS) * WoU + q % UPS) * p.res_ld] : 0.f;
+              tmp[q] = p.res ? T::load(p.res, rbase + ((long)(dy0 + q / UPS) * WoU + q % UPS) * p.res_ld)
+                             : 0.f;
 #pragma unroll
             for (int q = 0; q < RG * UPS; ++q) {
               const float o = v + tmp[q];
-              op[((long)(dy0 + q / UPS) * WoU + q % UPS) * p.out_ld] = p.relu ? fmaxf(o, 0.f) : o;
+              T::store(p.out, obase + ((long)(dy0 + q / UPS) * WoU + q % UPS) * p.out_ld,
+                       p.relu ? fmaxf(o, 0.f) : o);
             }
           }
         }
@@ -260,30 +302,30 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvK p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int UPS = 1, int BK = 16>
+template <typename T, int BM, int BN, int WM, int WN, int UPS = 1, int KQ = 4>
 static int launch(ConvK k, hipStream_t s) {
   k.nbx = (k.Cout + BN - 1) / BN;
   k.nby = (k.M + BM - 1) / BM;
-  hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, UPS, BK>), dim3(k.nbx * k.nby), dim3(256),
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, UPS, KQ>), dim3(k.nbx * k.nby), dim3(256),
                      0, s, k);
   return (int)hipGetLastError();
 }
 
-// the upsample-scatter epilogue and the BK = 32 variant are instantiated for the two small tiles
-template <int BM, int BN, int WM, int WN>
-static int launch_small(const ConvK &k, int bk, hipStream_t s) {
-  if (bk == 32 && k.ups == 1 && (k.Cin & 31) == 0) return launch<BM, BN, WM, WN, 1, 32>(k, s);
+// the upsample-scatter epilogue and the long-chunk (KQ = 8) variant exist for the small tiles
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_small(const ConvK &k, int kq, hipStream_t s) {
+  if (kq == 8 && k.ups == 1) return launch<T, BM, BN, WM, WN, 1, 8>(k, s);
   switch (k.ups) {
-    case 1: return launch<BM, BN, WM, WN, 1>(k, s);
-    case 2: return launch<BM, BN, WM, WN, 2>(k, s);
-    case 4: return launch<BM, BN, WM, WN, 4>(k, s);
-    case 8: return launch<BM, BN, WM, WN, 8>(k, s);
+    case 1: return launch<T, BM, BN, WM, WN, 1>(k, s);
+    case 2: return launch<T, BM, BN, WM, WN, 2>(k, s);
+    case 4: return launch<T, BM, BN, WM, WN, 4>(k, s);
+    case 8: return launch<T, BM, BN, WM, WN, 8>(k, s);
     default: return SHAPY_EINVAL;
   }
 }
 
 int conv_tile_auto(int M, int Cout) {
-  // Measured on MI355X at B = 64 (tools/conv_bench.py, profiles/conv_bench_r01.txt): the
+  // Measured on MI355X at B = 64 (tools/conv_bench.py, profiles/conv_bench_r01*.txt): the
   // kernel is latency-bound, so the smallest tiles (wave tile 16x48 / 32x32, 8 waves per
   // SIMD) beat the large ones on every HRNet class.  Choose the N tile (48 or 64) that pads
   // Cout least; on a tie take 64 unless that leaves too few workgroups to fill 256 CUs.
@@ -294,8 +336,28 @@ int conv_tile_auto(int M, int Cout) {
   return mt * (p64 / 64) >= 512 ? SHAPY_TILE_64x64 : SHAPY_TILE_64x48;
 }
 
-int conv2d_f32(const ShapyConv &d, hipStream_t s) {
-  if (d.Cin <= 0 || (d.Cin & 15) || (d.in_ld & 3) || d.ksize < 1 || d.stride < 1 || d.ups < 1)
+template <typename T>
+static int dispatch(const ConvK &k, int tile, int kq, hipStream_t s) {
+  switch (tile) {
+    case SHAPY_TILE_64x48: return launch_small<T, 64, 48, 4, 1>(k, kq, s);
+    case SHAPY_TILE_64x64: return launch_small<T, 64, 64, 2, 2>(k, kq, s);
+    case SHAPY_TILE_128x48: return launch<T, 128, 48, 4, 1>(k, s);
+    case SHAPY_TILE_128x64: return launch<T, 128, 64, 4, 1>(k, s);
+    case SHAPY_TILE_64x96: return launch<T, 64, 96, 2, 2>(k, s);
+    case SHAPY_TILE_128x96: return launch<T, 128, 96, 2, 2>(k, s);
+    case SHAPY_TILE_64x128: return launch<T, 64, 128, 2, 2>(k, s);
+    case SHAPY_TILE_128x128: return launch<T, 128, 128, 2, 2>(k, s);
+    case SHAPY_TILE_256x48: return launch<T, 256, 48, 4, 1>(k, s);
+    case SHAPY_TILE_256x64: return launch<T, 256, 64, 4, 1>(k, s);
+    default: return SHAPY_EINVAL;
+  }
+}
+
+int conv2d(const ShapyConv &d, hipStream_t s) {
+  const bool bf16 = d.dtype == SHAPY_DTYPE_BF16;
+  if (d.dtype != SHAPY_DTYPE_F32 && !bf16) return SHAPY_EINVAL;
+  const int esz = bf16 ? 2 : 4, eps = 16 / esz;          // element size, elements per slot
+  if (d.Cin <= 0 || d.Cin % (4 * eps) || d.in_ld % eps || d.ksize < 1 || d.stride < 1 || d.ups < 1)
     return SHAPY_EINVAL;
   if (((uintptr_t)d.in | (uintptr_t)d.wgt) & 15) return SHAPY_EINVAL;
   ConvK k;
@@ -305,38 +367,25 @@ int conv2d_f32(const ShapyConv &d, hipStream_t s) {
   k.Cout = d.Cout; k.ks = d.ksize; k.stride = d.stride; k.pad = d.pad;
   k.out_ld = d.out_ld; k.out_coff = d.out_coff; k.res_ld = d.res_ld; k.res_coff = d.res_coff;
   k.relu = d.relu; k.ups = d.ups;
-  const unsigned long long in_bytes = 4ull * d.B * d.Hi * d.Wi * d.in_ld;
-  const unsigned long long wgt_bytes = 4ull * d.Cout * d.ksize * d.ksize * d.Cin;
+  const unsigned long long in_bytes = (unsigned long long)esz * d.B * d.Hi * d.Wi * d.in_ld;
+  const unsigned long long wgt_bytes = (unsigned long long)esz * d.Cout * d.ksize * d.ksize * d.Cin;
   if (in_bytes >= 0x7fffffffull || wgt_bytes >= 0x7fffffffull) return SHAPY_EINVAL;   // 32-bit offsets
   k.in_bytes = (unsigned)in_bytes; k.wgt_bytes = (unsigned)wgt_bytes;
   if (k.M <= 0 || k.Cout <= 0) return SHAPY_OK;
   // d.tile: low byte = SHAPY_TILE_* (0 = auto).  Tuning knobs of tools/conv_bench.py:
-  // 0x100 / 0x400 force the XCD-contiguous workgroup order on / off, 0x200 / 0x800 force
-  // BK = 32 / 16.  Defaults (profiles/conv_bench_r01*.txt): XCD-contiguous always (+2..7 %),
-  // BK 32 whenever the K loop is long enough to stay pipelined (+6..20 % on the 14x14 / 7x7
-  // layers, slower on K = 64).
+  // 0x400 disables the XCD-contiguous workgroup order, 0x200 / 0x800 force the long (8 slots =
+  // 128-byte rows) / short (4 slots) K chunk.  Defaults (profiles/conv_bench_r01*.txt):
+  // XCD-contiguous always (+2..7 %), long chunks whenever the K loop stays pipelined
+  // (K >= 512 elements per slot-width: +6..20 % on the 14x14 / 7x7 layers, slower on K = 64).
   k.swz = (d.tile & 0x400) ? 0 : 1;
-  int bk = (k.ks * k.ks * k.Cin >= 512 && (k.Cin & 31) == 0) ? 32 : 16;
-  if (d.tile & 0x200) bk = 32;
-  if (d.tile & 0x800) bk = 16;
+  const int Kc = k.ks * k.ks * k.Cin;
+  int kq = (Kc >= 128 * eps && k.Cin % (8 * eps) == 0) ? 8 : 4;
+  if ((d.tile & 0x200) && k.Cin % (8 * eps) == 0) kq = 8;
+  if (d.tile & 0x800) kq = 4;
   int tile = (d.tile & 0xff) ? (d.tile & 0xff) : conv_tile_auto(k.M, k.Cout);
   if (k.ups != 1 && tile != SHAPY_TILE_64x48 && tile != SHAPY_TILE_64x64)
     tile = (k.Cout % 64 == 0 && k.Cout % 48 != 0) ? SHAPY_TILE_64x64 : SHAPY_TILE_64x48;
-  switch (tile) {
-    case SHAPY_TILE_256x48: return launch<256, 48, 4, 1>(k, s);
-    case SHAPY_TILE_128x96: return launch<128, 96, 2, 2>(k, s);
-    case SHAPY_TILE_128x128: return launch<128, 128, 2, 2>(k, s);
-    case SHAPY_TILE_256x64: return launch<256, 64, 4, 1>(k, s);
-    case SHAPY_TILE_64x48: return launch_small<64, 48, 4, 1>(k, bk, s);
-    case SHAPY_TILE_64x96: return launch<64, 96, 2, 2>(k, s);
-    case SHAPY_TILE_64x128: return launch<64, 128, 2, 2>(k, s);
-    case SHAPY_TILE_64x64: return launch_small<64, 64, 2, 2>(k, bk, s);
-    case SHAPY_TILE_128x48: return launch<128, 48, 4, 1>(k, s);
-    case SHAPY_TILE_128x64: return launch<128, 64, 4, 1>(k, s);
-    case SHAPY_TILE_256x96: return launch<256, 96, 4, 1>(k, s);
-    case SHAPY_TILE_256x128: return launch<256, 128, 2, 2>(k, s);
-    default: return SHAPY_EINVAL;
-  }
+  return bf16 ? dispatch<BF16>(k, tile, kq, s) : dispatch<F32>(k, tile, kq, s);
 }
 
 }  // namespace shapy

@@ -8,10 +8,22 @@ namespace shapy {
 
 // ---- stem: conv3x3 s2 p1, 3 -> 64 channels, NCHW input -> NHWC output, folded BN + ReLU ----
 // (hrnet.py:427-429).  K = 27 is too small for the matrix cores; 0.5 % of the network's MACs.
+__device__ __forceinline__ void store_elem(float *p, float v) { *p = v; }
+__device__ __forceinline__ void store_elem(unsigned short *p, float v) {
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);                      // bf16, round to nearest even
+  *p = (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float load_elem(const float *p) { return *p; }
+__device__ __forceinline__ float load_elem(const unsigned short *p) {
+  return __uint_as_float((unsigned)*p << 16);
+}
+
+template <typename OutT>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float *__restrict__ in,
                                                         const float *__restrict__ wgt,
                                                         const float *__restrict__ bias,
-                                                        float *__restrict__ out, int B, int H, int W,
+                                                        OutT *__restrict__ out, int B, int H, int W,
                                                         int Ho, int Wo, int out_ld) {
   __shared__ float w[27 * 64];   // w[k][n], k = (kh*3+kw)*3 + c
   for (int i = threadIdx.x; i < 27 * 64; i += 256) {
@@ -47,21 +59,22 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float *__restrict_
       }
     }
   }
-  float *o = out + pix * out_ld + g * 8;
+  OutT *o = out + pix * out_ld + g * 8;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = fmaxf(acc[i] + bias[g * 8 + i], 0.f);
+  for (int i = 0; i < 8; ++i) store_elem(o + i, fmaxf(acc[i] + bias[g * 8 + i], 0.f));
 }
 
 // ---- spatial mean over H*W (hrnet.py:484) ----
-__global__ void mean_pool_kernel(const float *__restrict__ in, float *__restrict__ out, int HW,
+template <typename InT>
+__global__ void mean_pool_kernel(const InT *__restrict__ in, float *__restrict__ out, int HW,
                                  int C, int in_ld, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int c = (int)(i % C);
   const long b = i / C;
-  const float *p = in + b * HW * in_ld + c;
+  const InT *p = in + b * HW * in_ld + c;
   float s = 0.f;
-  for (int k = 0; k < HW; ++k) s += p[(long)k * in_ld];
+  for (int k = 0; k < HW; ++k) s += load_elem(p + (long)k * in_ld);
   out[i] = s / (float)HW;
 }
 
@@ -93,9 +106,11 @@ static int get_lanes(Lanes **out) {
   return SHAPY_OK;
 }
 
-int hrnet_run_f32(const ShapyOp *ops, int n_ops, const float *weights, const float *input,
-                  float *ws, int64_t ws_per_img, float *features_out, int B, int H, int W,
-                  int multi_stream, hipStream_t main) {
+int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *input, void *ws,
+              int64_t ws_per_img, float *features_out, int B, int H, int W, int multi_stream,
+              int dtype, hipStream_t main) {
+  const int esz = dtype == SHAPY_DTYPE_BF16 ? 2 : 4;
+  const float *wf32 = reinterpret_cast<const float *>(weights);   // biases + stem weights
   Lanes *L = nullptr;
   if (multi_stream) {
     int rc = get_lanes(&L);
@@ -138,31 +153,47 @@ int hrnet_run_f32(const ShapyOp *ops, int n_ops, const float *weights, const flo
         // lane-0 work enqueued after the fork point must not delay later forks
       }
     }
-    auto buf = [&](int64_t off) -> float * { return off < 0 ? nullptr : ws + off * (int64_t)B; };
+    auto buf = [&](int64_t off) -> char * {
+      return off < 0 ? nullptr : (char *)ws + off * (int64_t)B * esz;
+    };
     if (o.type == SHAPY_OP_CONV) {
       ShapyConv d;
       d.in = buf(o.in_off);
-      d.wgt = weights + o.wgt_off;
-      d.bias = o.bias_off >= 0 ? weights + o.bias_off : nullptr;
+      d.wgt = (const char *)weights + o.wgt_off * esz;
+      d.bias = o.bias_off >= 0 ? wf32 + o.bias_off : nullptr;
+      d.dtype = dtype;
       d.res = buf(o.res_off);
       d.out = buf(o.out_off);
       d.B = B; d.Hi = o.Hi; d.Wi = o.Wi; d.Cin = o.Cin; d.in_ld = o.in_ld;
       d.Ho = o.Ho; d.Wo = o.Wo; d.Cout = o.Cout; d.ksize = o.ksize; d.stride = o.stride;
       d.pad = o.pad; d.out_ld = o.out_ld; d.out_coff = o.out_coff; d.res_ld = o.res_ld;
       d.res_coff = o.res_coff; d.relu = o.relu; d.ups = o.ups; d.tile = o.tile;
-      int rc = conv2d_f32(d, s);
+      int rc = conv2d(d, s);
       if (rc) return rc;
     } else if (o.type == SHAPY_OP_STEM) {
       if (o.Cin != 3 || o.Cout != 64 || o.ksize != 3 || o.stride != 2) return SHAPY_EINVAL;
       const long npix = (long)B * o.Ho * o.Wo;
-      hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((npix + 31) / 32)), dim3(256), 0, s,
-                         input, weights + o.wgt_off, weights + o.bias_off, buf(o.out_off), B, H, W,
-                         o.Ho, o.Wo, o.out_ld);
+      // the stem's own weights stay float32 (wgt_off counts float32 elements for this op)
+      const dim3 grid((unsigned)((npix + 31) / 32));
+      if (esz == 4)
+        hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, s, input, wf32 + o.wgt_off,
+                           wf32 + o.bias_off, (float *)buf(o.out_off), B, H, W, o.Ho, o.Wo, o.out_ld);
+      else
+        hipLaunchKernelGGL(stem_conv_kernel<unsigned short>, grid, dim3(256), 0, s, input,
+                           wf32 + o.wgt_off, wf32 + o.bias_off, (unsigned short *)buf(o.out_off), B,
+                           H, W, o.Ho, o.Wo, o.out_ld);
       SHAPY_HIP_TRY(hipGetLastError());
     } else if (o.type == SHAPY_OP_MEANPOOL) {
       const long total = (long)B * o.Cin;
-      hipLaunchKernelGGL(mean_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                         buf(o.in_off), features_out, o.Hi * o.Wi, o.Cin, o.in_ld, total);
+      const dim3 grid((unsigned)((total + 255) / 256));
+      if (esz == 4)
+        hipLaunchKernelGGL(mean_pool_kernel<float>, grid, dim3(256), 0, s,
+                           (const float *)buf(o.in_off), features_out, o.Hi * o.Wi, o.Cin, o.in_ld,
+                           total);
+      else
+        hipLaunchKernelGGL(mean_pool_kernel<unsigned short>, grid, dim3(256), 0, s,
+                           (const unsigned short *)buf(o.in_off), features_out, o.Hi * o.Wi, o.Cin,
+                           o.in_ld, total);
       SHAPY_HIP_TRY(hipGetLastError());
     } else {
       return SHAPY_EINVAL;

@@ -14,7 +14,7 @@ methods is ever called.  ``forward`` compiles the tree once into
     (K-contiguous rows for the MFMA B operand), and
   * a flat op list (``ShapyOp[]``) over a liveness-packed NHWC activation workspace,
 
-and hands both to ``shapy_hrnet_run_f32`` (csrc/hrnet_ops.hip), which launches the
+and hands both to ``shapy_hrnet_run`` (csrc/hrnet_ops.hip), which launches the
 implicit-GEMM MFMA kernel (csrc/conv_igemm.hip) per conv with the residual add, ReLU, the
 nearest-upsample + add of the fuse layers and the channel concat fused into its epilogue.
 The independent branches of a HighResolutionModule are issued on separate HIP streams.
@@ -148,8 +148,8 @@ class _Buf:
 
 def _pack(items):
     """First-fit offset assignment.  items: [(start, end, size, obj)], closed intervals;
-    two items may share memory iff their intervals are disjoint.  Sets obj.off (4-float
-    aligned) and returns the arena size."""
+    two items may share memory iff their intervals are disjoint.  Sets obj.off (8-element
+    aligned: 16 bytes in bf16) and returns the arena size."""
     live, total = [], 0
     for start, end, size, obj in sorted(items, key=lambda it: (it[0], -it[2])):
         live = [x for x in live if x[2] >= start]
@@ -159,23 +159,29 @@ def _pack(items):
             if off + size <= o:
                 break
             off = max(off, o + s)
-        off = (off + 3) // 4 * 4
+        off = (off + 7) // 8 * 8
         obj.off = off
         live.append((off, size, end))
         total = max(total, off + size)
-    return (total + 3) // 4 * 4
+    return (total + 7) // 8 * 8
 
 
 class _Plan:
     """Flat op list + weight packing for one input resolution."""
 
-    def __init__(self):
+    def __init__(self, bf16=False):
+        self.bf16 = bf16
         self.ops = []          # dicts
         self.bufs = []
-        self.wchunks = []      # float32 numpy arrays
-        self.woff = 0
+        self.wchunks = []      # byte strings, each padded to 16 bytes
+        self.wbytes = 0
         self.epoch = 0
         self._pending_barrier = False
+
+    def padc(self, c):
+        """bf16 rows are consumed 32 channels at a time: 48-channel tensors are stored with 64
+        (zero weights / zero outputs in the pad channels)."""
+        return (c + 31) // 32 * 32 if self.bf16 else c
 
     def buf(self, H, W, C):
         b = _Buf(H, W, C)
@@ -185,14 +191,18 @@ class _Plan:
     def barrier(self):
         self._pending_barrier = True
 
-    def add_weights(self, arr):
-        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
-        off = self.woff
-        pad = (-arr.size) % 4
-        self.wchunks.append(arr)
-        if pad:
-            self.wchunks.append(np.zeros(pad, np.float32))
-        self.woff += arr.size + pad
+    def add_weights(self, arr, as_bf16=False):
+        """Appends a tensor to the weight blob; returns its offset in ELEMENTS of its own type
+        (float32, or bfloat16 for conv weights in bf16 mode)."""
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32).reshape(-1))
+        if as_bf16:
+            raw, esz = t.to(torch.bfloat16).view(torch.int16).numpy().tobytes(), 2
+        else:
+            raw, esz = t.numpy().tobytes(), 4
+        off = self.wbytes // esz
+        raw += b'\0' * ((-len(raw)) % 16)
+        self.wchunks.append(raw)
+        self.wbytes += len(raw)
         return off
 
     def op(self, **kw):
@@ -306,7 +316,9 @@ class HighResolutionNet(nn.Module):
         self._engine = {}
         self.multi_stream = True
         self.tile_overrides = {}
-        self.tile_flags = 0          # OR-ed into every conv's tile id (0x100 = XCD-contiguous)
+        self.tile_flags = 0          # OR-ed into every conv's tile id (tuning knobs)
+        #: 'f32' = exact-f32 MFMA (parity path); 'bf16' = bf16 weights/activations, f32 accumulate
+        self.compute_dtype = 'f32'
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
 
     # ---- construction helpers (mirror hrnet.py:301-424) ----
@@ -414,24 +426,32 @@ class HighResolutionNet(nn.Module):
         st['_engine'] = {}
         return st
 
-    def _build_plan(self, H, W):
-        P = _Plan()
+    def _build_plan(self, H, W, bf16=False):
+        P = _Plan(bf16)
         ov = self.tile_overrides
 
         def conv(conv_m, bn, inb, Hi, Wi, outb=None, res=None, relu=False, ups=1, lane=0,
                  out_ld=None, out_coff=0, res_ld=None, res_coff=0, name=''):
             ks, st, pad = conv_m.kernel_size[0], conv_m.stride[0], conv_m.padding[0]
             cin, cout = conv_m.in_channels, conv_m.out_channels
+            cin_p, cout_p = P.padc(cin), P.padc(cout)
+            assert inb.C == cin_p, (name, inb.C, cin_p)
             Ho, Wo = (Hi + 2 * pad - ks) // st + 1, (Wi + 2 * pad - ks) // st + 1
             w, b = _fold(conv_m, bn)
+            if (cin_p, cout_p) != (cin, cout):
+                wp = np.zeros((cout_p, ks, ks, cin_p), np.float32)
+                wp[:cout, :, :, :cin] = w
+                bp = np.zeros(cout_p, np.float32)
+                bp[:cout] = b
+                w, b = wp, bp
             if outb is None:
-                outb = P.buf(Ho * ups, Wo * ups, cout)
-            P.op(type=_lib.OP_CONV, lane=lane, inb=inb, outb=outb, resb=res, Hi=Hi, Wi=Wi, Cin=cin,
-                 in_ld=inb.C, Ho=Ho, Wo=Wo, Cout=cout, ksize=ks, stride=st, pad=pad,
+                outb = P.buf(Ho * ups, Wo * ups, cout_p)
+            P.op(type=_lib.OP_CONV, lane=lane, inb=inb, outb=outb, resb=res, Hi=Hi, Wi=Wi, Cin=cin_p,
+                 in_ld=inb.C, Ho=Ho, Wo=Wo, Cout=cout_p, ksize=ks, stride=st, pad=pad,
                  out_ld=out_ld or outb.C, out_coff=out_coff,
                  res_ld=(res_ld or (res.C if res is not None else 0)), res_coff=res_coff,
                  relu=int(relu), ups=ups, tile=_lib.TILES[ov.get(name, 'auto')] | self.tile_flags,
-                 wgt_off=P.add_weights(w), bias_off=P.add_weights(b))
+                 wgt_off=P.add_weights(w, as_bf16=P.bf16), bias_off=P.add_weights(b))
             return outb, Ho, Wo
 
         # stem (hrnet.py:427-432)
@@ -441,7 +461,7 @@ class HighResolutionNet(nn.Module):
         P.op(type=_lib.OP_STEM, lane=0, inb=None, outb=s1, resb=None, Hi=H, Wi=W, Cin=3, in_ld=0,
              Ho=H1, Wo=W1, Cout=64, ksize=3, stride=2, pad=1, out_ld=64, out_coff=0, res_ld=0,
              res_coff=0, relu=1, ups=1, tile=0, wgt_off=P.add_weights(w.reshape(64, 27)),
-             bias_off=P.add_weights(b))
+             bias_off=P.add_weights(b))      # the stem keeps float32 weights in both modes
         x, Hc, Wc = conv(self.conv2, self.bn2, s1, H1, W1, relu=True, name='conv2')
 
         def bottleneck(m, x, Hc, Wc, lane=0, side_lane=None, name=''):
@@ -580,11 +600,12 @@ class HighResolutionNet(nn.Module):
         return P
 
     def _compile(self, H, W, device):
-        key = (H, W, str(device))
+        bf16 = self.compute_dtype == 'bf16'
+        key = (H, W, str(device), bf16)
         eng = self._engine.get(key)
         if eng is not None:
             return eng
-        P = self._build_plan(H, W)
+        P = self._build_plan(H, W, bf16)
         ws_per_img = P.allocate()
         n = len(P.ops)
         arr = (_lib.ShapyOp * n)()
@@ -597,9 +618,11 @@ class HighResolutionNet(nn.Module):
             a.in_off = -2 if o['type'] == _lib.OP_STEM else o['inb'].off
             a.out_off = -1 if o['outb'] is None else o['outb'].off
             a.res_off = -1 if o['resb'] is None else o['resb'].off
-        weights = torch.from_numpy(np.concatenate(P.wchunks)).to(device)
+        blob = np.frombuffer(b''.join(P.wchunks), dtype=np.uint8)
+        weights = torch.from_numpy(blob.copy()).to(device)
         eng = dict(ops=arr, n_ops=n, weights=weights, ws_per_img=ws_per_img, plan=P, ws=None,
-                   feat_dim=P.ops[-1]['Cin'])
+                   feat_dim=P.ops[-1]['Cin'], esz=2 if bf16 else 4,
+                   dtype=_lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32)
         self._engine[key] = eng
         return eng
 
@@ -613,15 +636,14 @@ class HighResolutionNet(nn.Module):
             raise ValueError('HRNet input height/width must be multiples of 32')
         x = x.contiguous().float()
         eng = self._compile(H, W, x.device)
-        need = eng['ws_per_img'] * B
+        need = eng['ws_per_img'] * B * eng['esz']
         if eng['ws'] is None or eng['ws'].numel() < need:
-            eng['ws'] = torch.empty(need, dtype=torch.float32, device=x.device)
+            eng['ws'] = torch.empty(need, dtype=torch.uint8, device=x.device)
         feat = torch.empty(B, eng['feat_dim'], dtype=torch.float32, device=x.device)
-        rc = lib.shapy_hrnet_run_f32(eng['ops'], eng['n_ops'], _lib.ptr(eng['weights']),
-                                     _lib.ptr(x), _lib.ptr(eng['ws']), eng['ws_per_img'],
-                                     _lib.ptr(feat), B, H, W, int(self.multi_stream),
-                                     _lib.current_stream())
-        _lib.check(rc, 'shapy_hrnet_run_f32')
+        rc = lib.shapy_hrnet_run(eng['ops'], eng['n_ops'], _lib.ptr(eng['weights']), _lib.ptr(x),
+                                 _lib.ptr(eng['ws']), eng['ws_per_img'], _lib.ptr(feat), B, H, W,
+                                 int(self.multi_stream), eng['dtype'], _lib.current_stream())
+        _lib.check(rc, 'shapy_hrnet_run')
         return {'concat': feat}
 
 

@@ -236,7 +236,7 @@ class SMPLX(nn.Module):
         d.ksize = 1; d.stride = 1; d.pad = 0
         d.out_ld = N; d.out_coff = 0; d.res_ld = N; d.res_coff = 0
         d.relu = 0; d.ups = 1; d.tile = 0
-        _lib.check(lib.shapy_conv2d_f32(ctypes_byref(d), stream), 'shapy_conv2d_f32 (blend shapes)')
+        _lib.check(lib.shapy_conv2d(ctypes_byref(d), stream), 'shapy_conv2d (blend shapes)')
 
     def forward_shape(self, betas=None):
         """SMPL.forward_shape (body_models.py:296-306)."""

@@ -40,8 +40,9 @@ def _conv_call(lib, x, w, b, res=None, relu=False, stride=1, pad=0, ups=1, tile=
     Ho = (Hi + 2 * pad - ks) // stride + 1
     Wo = (Wi + 2 * pad - ks) // stride + 1
     if out is None:
-        out = torch.empty(B, Ho * ups, Wo * ups, O, device=x.device)
+        out = torch.empty(B, Ho * ups, Wo * ups, O, device=x.device, dtype=x.dtype)
     d = _lib.ShapyConv()
+    d.dtype = _lib.DTYPE_BF16 if x.dtype == torch.bfloat16 else _lib.DTYPE_F32
     d.in_ = x.data_ptr(); d.wgt = w.data_ptr(); d.bias = b.data_ptr() if b is not None else None
     d.res = res.data_ptr() if res is not None else None
     d.out = out.data_ptr()
@@ -51,7 +52,7 @@ def _conv_call(lib, x, w, b, res=None, relu=False, stride=1, pad=0, ups=1, tile=
     d.out_ld = out_ld or O; d.out_coff = out_coff
     d.res_ld = (out_ld or O) if res is not None else 0; d.res_coff = out_coff if res is not None else 0
     d.relu = int(relu); d.ups = ups; d.tile = tile
-    rc = lib.shapy_conv2d_f32(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    rc = lib.shapy_conv2d(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
     torch.cuda.synchronize()
     return out
@@ -111,6 +112,40 @@ def test_conv_kernel_vs_float64(lib, case):
     assert err < 2e-5, err
 
 
+BF16_CASES = [
+    # B, H, W, Cin, Cout, ks, stride, ups, res, relu, tile
+    (2, 12, 12, 64, 64, 3, 1, 1, True, True, 0),
+    (3, 10, 14, 96, 96, 3, 1, 1, True, False, 0),
+    (2, 9, 9, 64, 256, 1, 1, 1, False, False, 0),
+    (1, 7, 7, 512, 2048, 1, 1, 1, True, True, 0),
+    (2, 15, 13, 96, 192, 3, 2, 1, False, True, 0),
+    (2, 4, 4, 192, 64, 1, 1, 4, True, True, 0),
+    (2, 3, 3, 384, 96, 1, 1, 8, True, True, 0),
+    (2, 6, 6, 32, 48, 3, 1, 1, False, True, 5),
+]
+
+
+@pytest.mark.parametrize('case', BF16_CASES, ids=[str(c) for c in BF16_CASES])
+def test_conv_kernel_bf16_vs_float64(lib, case):
+    """bf16 storage, f32 accumulation: against float64 on the SAME bf16-rounded operands the
+    only error left is the final rounding of the output to bf16 (2^-9 relative)."""
+    B, H, W, Cin, Cout, ks, stride, ups, use_res, relu, tile = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, H, W, Cin, generator=g).bfloat16().cuda()
+    w = (torch.randn(Cout, ks, ks, Cin, generator=g) / np.sqrt(ks * ks * Cin)).bfloat16().cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    pad = ks // 2
+    Ho = (H + 2 * pad - ks) // stride + 1
+    Wo = (W + 2 * pad - ks) // stride + 1
+    res = torch.randn(B, Ho * ups, Wo * ups, Cout, generator=g).bfloat16().cuda() if use_res else None
+    out = _conv_call(lib, x, w, b, res, relu, stride, pad, ups, tile)
+    assert out.dtype == torch.bfloat16
+    ref = _conv_ref(x.float(), w.float(), b, res.float() if use_res else None, relu, stride, pad, ups)
+    err = (out.float().cpu().double() - ref).abs()
+    tol = ref.abs() * 2.0 ** -8 + 1e-5
+    assert (err <= tol).all(), float((err - tol).max())
+
+
 def test_conv_concat_offset_and_inplace_residual(lib):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 7, 7, 192, generator=g).cuda()
@@ -165,6 +200,27 @@ def test_hrnet_features_vs_reference_golden(network, golden_dir, tag, b, s, mult
     err = np.abs(feat.cpu().numpy() - g[tag]).max()
     print(tag, 'multi_stream', multi_stream, 'max abs err', err, 'scale', np.abs(g[tag]).max())
     assert err < 1e-4, err
+
+
+@pytest.mark.parametrize('tag,b,s', [('b2_64', 2, 64), ('b1_224', 1, 224)])
+def test_hrnet_bf16_features_vs_f32_golden(network, golden_dir, tag, b, s):
+    """BASELINE configs[2]: bf16 weights/activations, f32 accumulate.  It does not meet the 1e-4
+    bar (that is the f32 path's job); its error is reported and bounded separately."""
+    from shapy_amd.utils import synthetic as syn
+    g = np.load(osp.join(golden_dir, 'hrnet_golden.npz'))
+    x = torch.from_numpy(syn.synthetic_images(b, s, 0)).cuda()
+    network.backbone.compute_dtype = 'bf16'
+    try:
+        with torch.no_grad():
+            feat = network.backbone(x)['concat']
+        torch.cuda.synchronize()
+    finally:
+        network.backbone.compute_dtype = 'f32'
+    ref = g[tag]
+    err = np.abs(feat.cpu().numpy() - ref)
+    rel = err.max() / np.abs(ref).max()
+    print(tag, 'bf16 max abs err', err.max(), 'mean abs err', err.mean(), 'rel to max', rel)
+    assert rel < 0.05, rel
 
 
 def test_full_forward_vs_reference_golden(network, golden_dir):

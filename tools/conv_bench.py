@@ -3,7 +3,7 @@
     python tools/conv_bench.py [--batch 64] [--size 224] [--tiles auto,256x48,...] [--out file]
 
 For every distinct (Hi, Cin, Cout, ksize, stride, ups, residual) class of the backbone's op
-list it times shapy_conv2d_f32 alone on the GPU (HIP events, single stream) and prints
+list it times shapy_conv2d alone on the GPU (HIP events, single stream) and prints
 count x time, TFLOP/s and the share of the summed time -- the tuning table behind
 conv_tile_auto() in csrc/conv_igemm.hip.
 """
@@ -68,12 +68,12 @@ def main():
             d.out_ld = Cout; d.out_coff = 0; d.res_ld = Cout if has_res else 0; d.res_coff = 0
             d.relu = int(relu); d.ups = ups; d.tile = _lib.TILES[tile]
             for _ in range(2):
-                rc = lib.shapy_conv2d_f32(ctypes.byref(d), stream)
+                rc = lib.shapy_conv2d(ctypes.byref(d), stream)
                 assert rc == 0, (rc, key, tile)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.iters):
-                lib.shapy_conv2d_f32(ctypes.byref(d), stream)
+                lib.shapy_conv2d(ctypes.byref(d), stream)
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / args.iters
             rows.append(dict(key=key, count=count, tile=tile, us=us, tflops=flop / us / 1e6,
