@@ -62,8 +62,9 @@ def cpu_baseline(batch, size, budget_s=15.0):
     import torch
     import __graft_entry__ as ge
     from shapy_amd.utils import synthetic as syn
-    cores = torch.get_num_threads()
-    b = min(batch, 8)
+    cores = min(torch.get_num_threads(), 64)      # more threads only add scheduling noise here
+    torch.set_num_threads(cores)
+    b = min(batch, 16)
     x = syn.synthetic_images(b, size, 1)
     n = 0
     import oracle.hrnet_torch as ht

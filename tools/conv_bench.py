@@ -30,10 +30,13 @@ def main():
     ap.add_argument('--iters', type=int, default=8)
     ap.add_argument('--out', default='')
     ap.add_argument('--filter', default='', help='Hi,Cin,Cout,ksize: run only this class')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     args = ap.parse_args()
     lib = _lib.load()
     net = HighResolutionNet(default_config().network.smplx.backbone.hrnet)
-    P = net._build_plan(args.size, args.size)
+    bf16 = args.dtype == 'bf16'
+    tdt = torch.bfloat16 if bf16 else torch.float32
+    P = net._build_plan(args.size, args.size, bf16)
     classes = collections.OrderedDict()
     for o in P.ops:
         if o['type'] != _lib.OP_CONV:
@@ -51,10 +54,10 @@ def main():
             continue
         pad = ks // 2
         Ho, Wo = (Hi + 2 * pad - ks) // st + 1, (Wi + 2 * pad - ks) // st + 1
-        x = torch.randn(B, Hi, Wi, Cin, device='cuda')
-        w = torch.randn(Cout, ks, ks, Cin, device='cuda') * 0.05
+        x = torch.randn(B, Hi, Wi, Cin, device='cuda').to(tdt)
+        w = (torch.randn(Cout, ks, ks, Cin, device='cuda') * 0.05).to(tdt)
         b = torch.randn(Cout, device='cuda')
-        out = torch.empty(B, Ho * ups, Wo * ups, Cout, device='cuda')
+        out = torch.empty(B, Ho * ups, Wo * ups, Cout, device='cuda', dtype=tdt)
         res = torch.randn_like(out) if has_res else None
         flop = 2.0 * B * Ho * Wo * Cout * Cin * ks * ks
         for tile in args.tiles.split(','):
@@ -67,6 +70,7 @@ def main():
             d.ksize, d.stride, d.pad = ks, st, pad
             d.out_ld = Cout; d.out_coff = 0; d.res_ld = Cout if has_res else 0; d.res_coff = 0
             d.relu = int(relu); d.ups = ups; d.tile = _lib.TILES[tile]
+            d.dtype = _lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32
             for _ in range(2):
                 rc = lib.shapy_conv2d(ctypes.byref(d), stream)
                 assert rc == 0, (rc, key, tile)
