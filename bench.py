@@ -66,32 +66,11 @@ def cpu_baseline(batch, size, budget_s=15.0):
     torch.set_num_threads(cores)
     b = min(batch, 16)
     x = syn.synthetic_images(b, size, 1)
-    n = 0
-    import oracle.hrnet_torch as ht
-    from oracle import body_np, measure
-    sd = syn.synthetic_state_dict([('backbone.' + k, s) for k, s in ht.state_dict_spec()], 0)
-    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
-    spec = [('regressor.module.layer_000.0.weight', (1024, 2193)),
-            ('regressor.module.layer_000.0.bias', (1024,)),
-            ('regressor.module.layer_001.0.weight', (1024, 1024)),
-            ('regressor.module.layer_001.0.bias', (1024,)),
-            ('regressor.module.output_layer.weight', (145, 1024)),
-            ('regressor.module.output_layer.bias', (145,))]
-    w = syn.synthetic_state_dict(spec, 0)
-    layers = [(w[spec[2 * i][0]], w[spec[2 * i + 1][0]]) for i in range(3)]
-    model = syn.make_synthetic_smplx(0)
-    data = osp.join(ROOT, 'shapy_amd', 'data')
-    lm = measure.load_landmarks(osp.join(data, 'measurement_defitions.yaml'),
-                                osp.join(data, 'smplx_measurements.yaml'))
-    xt = torch.from_numpy(x)
-    with torch.no_grad():                                   # untimed warm-up pass
-        ht.hrnet_forward(sd, xt, prefix='backbone.')
-    t0 = time.perf_counter()
+    state = ge.oracle_state(0)
+    ge.oracle_forward(x[:1], state=state)                    # untimed warm-up pass
+    n, t0 = 0, time.perf_counter()
     while True:
-        with torch.no_grad():
-            feat = ht.hrnet_forward(sd, xt, prefix='backbone.').numpy()
-        out = body_np.regressor_head(feat, layers, model)
-        measure.body_measurements(out['stages'][-1]['v_shaped'][:, model['f']], lm)
+        ge.oracle_forward(x, state=state)
         n += b
         if time.perf_counter() - t0 > budget_s:
             break

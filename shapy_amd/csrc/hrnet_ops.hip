@@ -149,8 +149,6 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
         }
         s = L->s[li];
         dirty[li] = true;
-      } else {
-        // lane-0 work enqueued after the fork point must not delay later forks
       }
     }
     auto buf = [&](int64_t off) -> char * {

@@ -5,13 +5,16 @@ body_measurements.py:17-246): same config keys (``meas_definition_path``,
 ``meas_vertices_path``, ``max_collisions``), same ``forward(triangles [B,F,3,3])`` signature
 and the same ``{'measurements': {name: {'tensor': [B]}}}`` result.
 
-Two execution paths, both entirely on the GPU:
-  * ``forward(triangles)`` -- the reference's signature.  Runs the intersection *operator*
-    (``MeshMeshIntersection``) per plane and then the fused hull kernel... the operator
-    result is consumed exactly like body_measurements.py:141-179 does.
-  * ``forward_vertices(v_shaped, faces)`` -- what the regressor calls: one fused launch pair
-    (csrc/measure.hip) straight from ``v_shaped`` and the int32 face table; the
-    ``[B,F,3,3]`` triangle tensor (752 KB per body) is never materialised.
+Two entry points, one fused GPU implementation (csrc/measure.hip: a scan over the faces
+computes the signed-volume partial sums and the plane/triangle hits of all three planes, then
+one workgroup per (mesh, plane) sorts the points in LDS and walks the 2-D convex hull):
+  * ``forward(triangles [B,F,3,3])`` -- the reference's signature; the triangle soup is viewed as
+    a mesh with 3F vertices.
+  * ``measure_vertices(v_shaped, faces)`` -- what the regressor calls: reads ``v_shaped`` and the
+    int32 face table directly, so the ``[B,F,3,3]`` triangle tensor (752 KB per body) is never
+    materialised.
+The intersection *operator* itself (``MeshMeshIntersection``) is exported separately for
+callers that want the raw collisions.
 """
 import ctypes
 import os.path as osp
