@@ -10,9 +10,10 @@ contiguous shard of the image list (data parallel, no exchange during the forwar
 per-person results (betas, the five measurements, v_shaped) are all-gathered with RCCL; rank 0
 writes ``<output_folder>/<results_folder>/predictions.npz`` in the HBW submission layout
 (``image_name``, ``v_shaped``; regressor/hbw_evaluation/test_submission_format.py:4-45) plus
-``betas`` and ``measurements``.  The dataset-specific ground-truth metrics of the reference's
-Evaluator (v2v, p2p-20k, mpjpe; evaluation.py:192-357) need the licensed HBW / SSP-3D data
-and are out of scope.
+``betas`` and ``measurements``.  The ground-truth metrics of the reference's Evaluator (v2v_t,
+p2p-20k, measurement errors; evaluation.py:192-357) run on the GPU through
+``shapy_amd.evaluation.Evaluator`` for datasets whose targets carry the ground-truth fields; the
+licensed HBW / SSP-3D readers themselves are out of scope.
 """
 import logging
 import os

@@ -232,6 +232,30 @@ int shapy_crop_resize_normalize_u8(const unsigned char *images, const int64_t *i
                                    int S, const float *mean_host, const float *std_host,
                                    void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Evaluator metrics (the step behind the hot path).
+ * Aligned point error: PointError(alignment)(est, gt) of regressor/human_shape/utils/metrics.py
+ * :335-365 with the alignments of :59-277 -- alignment 0 none, 1 translation, 2 scale,
+ * 3 procrustes -- as used by Evaluator._compute_v2v / _compute_mpjpe
+ * (regressor/human_shape/evaluation.py:120-225).   est, gt: [B,P,3] float32.
+ * Any of err_out [B,P], err_mean_out [B], aligned_out [B,P,3] (the aligned estimate the
+ * alignment objects return) may be NULL.
+ * ------------------------------------------------------------------------------------- */
+int shapy_aligned_point_error_f32(const float *est, const float *gt, int B, int P, int alignment,
+                                  float *err_out, float *err_mean_out, float *aligned_out,
+                                  void *stream);
+
+/* Point-to-point error between meshes of different topology (P2P-20k): v2vhdError.__call__
+ * (regressor/human_shape/utils/metrics.py:367-460; caller evaluation.py:227-262).  The two
+ * P x V point regressors are CSR (int32 rowptr [P+1], int32 col, float64 val); vertices are
+ * float64 [B,V,3] as in the reference.  align != 0 removes the mean offset of the regressed
+ * points.  err_out [B,P] float64, err_mean_out [B] float64 (may be NULL). */
+int shapy_p2p_error_f64(const int32_t *in_rowptr, const int32_t *in_col, const double *in_val,
+                        const int32_t *tgt_rowptr, const int32_t *tgt_col, const double *tgt_val,
+                        const double *input_verts, const double *target_verts, int B, int P,
+                        int V_in, int V_tgt, int align, double *err_out, double *err_mean_out,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

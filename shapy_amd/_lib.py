@@ -87,6 +87,9 @@ SIGNATURES = {
                                                 ctypes.c_int, vp]),
     'shapy_crop_resize_normalize_u8': (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int,
                                                       c_float_p, c_float_p, vp]),
+    'shapy_aligned_point_error_f32': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                     vp, vp, vp, vp]),
+    'shapy_p2p_error_f64': (ctypes.c_int, [vp] * 8 + [ctypes.c_int] * 5 + [vp, vp, vp]),
     'shapy_mesh_to_mesh_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 4),
     'shapy_mesh_to_mesh_f32': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, vp, vp, vp, ctypes.c_size_t, vp, vp]),

@@ -24,6 +24,7 @@ SOURCES = {
     'measure.hip': ['-ffp-contract=off'],
     'bvh.hip': ['-ffp-contract=off'],
     'preprocess.hip': ['-ffp-contract=off'],
+    'metrics.hip': [],
     'capi.hip': [],
 }
 COMMON = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
