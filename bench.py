@@ -89,8 +89,10 @@ def main():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--single-stream', action='store_true')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
-                    help='f32 = BASELINE configs[1] (headline); bf16 = configs[2] storage type')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f32x6', 'bf16'],
+                    help='f32 = BASELINE configs[1] (headline) on the f32 matrix-core path; '
+                         'f32x6 = same float32 tensors, products from the exact 3-way bf16 split '
+                         '(6 bf16 MFMAs per product); bf16 = configs[2] storage type')
     args = ap.parse_args()
 
     import numpy as np
@@ -158,7 +160,14 @@ def main():
     backbone_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     flop_img = conv_flop_per_image(net, args.size)
     achieved = flop_img * B / (backbone_ms * 1e-3) / 1e12
-    peak = F32_MFMA_PEAK_TFLOPS if args.dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
+    # f32x6 issues 6 bf16 MFMAs per float32 multiply-add: its matrix-core roof in algorithmic
+    # (float32) FLOP/s is the dense bf16 peak / 6
+    peak = {'f32': F32_MFMA_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS,
+            'f32x6': BF16_MFMA_PEAK_TFLOPS / 6.0}[args.dtype]
+    kernel = {'f32': 'conv_igemm_kernel<F32> (v_mfma_f32_16x16x4_f32)',
+              'bf16': 'conv_igemm_kernel<BF16> (v_mfma_f32_16x16x32_bf16)',
+              'f32x6': 'conv_x6_kernel (6 x v_mfma_f32_16x16x32_bf16 per f32 product; peak = '
+                       'dense bf16 peak / 6)'}[args.dtype]
     if rank == 0:
         res = {
             'metric': 'images/sec whole-node (HRNet+SMPL-X fwd), 224x224 bs=64; betas L2 vs CPU',
@@ -175,15 +184,18 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'HRNet-W48 + iterative regressor + SMPL-X + virtual '
                                    f'measurements, random-init weights, {args.size}x{args.size}, '
-                                   f'bs={B} per GPU, ' + ('fp32 (BASELINE configs[1])' if args.dtype == 'f32'
-                                                          else 'bf16 storage / f32 accumulate '
-                                                               '(BASELINE configs[2] precision)'),
+                                   f'bs={B} per GPU, ' + {
+                                       'f32': 'fp32 (BASELINE configs[1])',
+                                       'f32x6': 'fp32 tensors, bf16x6 split products '
+                                                '(BASELINE configs[1])',
+                                       'bf16': 'bf16 storage / f32 accumulate (BASELINE '
+                                               'configs[2] precision)'}[args.dtype],
                        'global_batch': world * B, 'parallelism': f'dp{world}',
                        'multi_stream': not args.single_stream},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': pmc_traffic(B, args.size) if args.dtype == 'f32' else None,
-                         'kernel': 'conv_igemm_f32_kernel (330 launches per backbone forward)',
+                         'kernel': kernel + ', 330 launches per backbone forward',
                          'flop_per_launch_group': flop_img * B,
                          'ms_per_launch_group': backbone_ms},
         }

@@ -60,7 +60,11 @@ const char *shapy_build_arch(void);
  * B=M.  Requirements: Cin % 16 == 0 (f32) / % 32 == 0 (bf16), in and wgt 16-byte aligned,
  * in_ld a multiple of 16 bytes; tensors smaller than 2 GiB (32-bit buffer offsets).
  * ------------------------------------------------------------------------------------- */
-enum { SHAPY_DTYPE_F32 = 0, SHAPY_DTYPE_BF16 = 1 };
+/* F32X6: float32 storage everywhere (same tensors as F32), products formed on the bf16 matrix
+ * cores from the exact 3-way bf16 split of both operands (6 MFMAs per product, f32
+ * accumulation; csrc/conv_x6.hip) -- float32-class accuracy, Cin only needs to be a multiple
+ * of 4. */
+enum { SHAPY_DTYPE_F32 = 0, SHAPY_DTYPE_BF16 = 1, SHAPY_DTYPE_F32X6 = 2 };
 
 typedef struct ShapyConv {
   const void *in;     /* [B, Hi, Wi, in_ld]   (first Cin channels of each pixel are used)   */

@@ -8,7 +8,8 @@ import os
 import os.path as osp
 
 _HERE = osp.dirname(osp.abspath(__file__))
-LIB_PATH = osp.join(_HERE, 'csrc', 'libshapy_hip.so')
+# SHAPY_HIP_LIB selects a variant build of the same library (kernel tuning experiments only)
+LIB_PATH = os.environ.get('SHAPY_HIP_LIB') or osp.join(_HERE, 'csrc', 'libshapy_hip.so')
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_i32_p = ctypes.POINTER(ctypes.c_int32)
@@ -52,7 +53,7 @@ class ShapySmplxModel(ctypes.Structure):
 
 OP_CONV, OP_STEM, OP_MEANPOOL = 0, 1, 2
 POSE_ROTMAT, POSE_CONT6D, POSE_AXIS_ANGLE = 0, 1, 2
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F32X6 = 0, 1, 2
 TILES = {'auto': 0, '256x48': 1, '128x96': 2, '128x128': 3, '256x64': 4, '64x48': 5,
          '64x96': 6, '64x128': 7, '64x64': 8, '128x48': 9, '128x64': 10}
 for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: conv2d)

@@ -18,6 +18,7 @@ ARCH = 'gfx950'
 
 SOURCES = {
     'conv_igemm.hip': [],
+    'conv_x6.hip': [],
     'hrnet_ops.hip': [],
     'body.hip': [],
     # bit-identical float32 decisions with the CPU oracle: no FMA contraction here
@@ -28,6 +29,9 @@ SOURCES = {
     'capi.hip': [],
 }
 COMMON = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
+# tuning experiments: SHAPY_HIPCC_FLAGS='-DSHAPY_MFMA_PRIO=2' SHAPY_HIP_LIB=/path/variant.so
+COMMON += os.environ.get('SHAPY_HIPCC_FLAGS', '').split()
+OUT = os.environ.get('SHAPY_HIP_LIB', OUT)
 
 
 def hipcc():
@@ -47,7 +51,7 @@ def build(force=False, verbose=False):
     if not force and osp.exists(OUT) and osp.getmtime(OUT) >= _newest_dep():
         return OUT
     cc = hipcc()
-    objdir = osp.join(CSRC, 'build')
+    objdir = osp.join(CSRC, 'build' if OUT.endswith('libshapy_hip.so') else 'build_' + osp.basename(OUT))
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(item):

@@ -20,7 +20,8 @@ extern "C" int shapy_hrnet_run(const ShapyOp *ops, int n_ops, const void *weight
                                int64_t ws_elems_per_image, float *features_out, int B, int H, int W,
                                int multi_stream, int dtype, void *stream) {
   if (!ops || n_ops <= 0 || B <= 0 || (H % 32) || (W % 32)) return SHAPY_EINVAL;
-  if (dtype != SHAPY_DTYPE_F32 && dtype != SHAPY_DTYPE_BF16) return SHAPY_EINVAL;
+  if (dtype != SHAPY_DTYPE_F32 && dtype != SHAPY_DTYPE_BF16 && dtype != SHAPY_DTYPE_F32X6)
+    return SHAPY_EINVAL;
   return shapy::hrnet_run(ops, n_ops, weights, input_nchw, workspace, ws_elems_per_image,
                           features_out, B, H, W, multi_stream, dtype, (hipStream_t)stream);
 }

@@ -1,0 +1,147 @@
+// Shared pieces of the implicit-GEMM convolution kernels (conv_igemm.hip, conv_x6.hip).
+#pragma once
+#include "common.h"
+
+namespace shapy {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct F32 {
+  using elem = float;
+  static constexpr int EPS = 4;       // elements per 16-byte slot
+  static __device__ __forceinline__ float load(const void *p, long i) {
+    return reinterpret_cast<const float *>(p)[i];
+  }
+  static __device__ __forceinline__ void store(void *p, long i, float v) {
+    reinterpret_cast<float *>(p)[i] = v;
+  }
+};
+
+struct BF16 {
+  using elem = unsigned short;
+  static constexpr int EPS = 8;
+  static __device__ __forceinline__ float load(const void *p, long i) {
+    return __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(p)[i] << 16);
+  }
+  static __device__ __forceinline__ void store(void *p, long i, float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);                    // round to nearest even
+    reinterpret_cast<unsigned short *>(p)[i] = (unsigned short)(u >> 16);
+  }
+};
+
+struct ConvK {
+  const void *in, *wgt, *res;
+  const float *bias;
+  void *out;
+  int M, Hi, Wi, Cin, in_ld, Ho, Wo, Cout, ks, stride, pad;
+  int out_ld, out_coff, res_ld, res_coff, relu, ups, swz, nbx, nby;
+  unsigned in_bytes, wgt_bytes;
+};
+
+// float32 storage, bf16x6 split arithmetic on the bf16 matrix cores (conv_x6.hip)
+int conv2d_x6(const ConvK &k, int tile, hipStream_t s);
+
+// workgroup -> tile.  Workgroup ids are dealt round-robin to the 8 XCDs (private L2s): with
+// swz every XCD gets a CONTIGUOUS run of tiles (n fastest, then m), so the tiles that share
+// A rows -- the N tiles of one M tile and the 3x3 halos of neighbouring M tiles -- hit the
+// same L2.  Speed only; correctness does not depend on the placement.
+__device__ __forceinline__ int conv_tile_index(const ConvK &p) {
+  int wg = blockIdx.x;
+  if (p.swz) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  return wg;
+}
+
+// Epilogue of a wave's TM x TN grid of 16x16 accumulator tiles (MFMA C layout: lane l holds
+// column l & 15, rows 4 * (l >> 4) .. + 3): bias (+ residual) (+ ReLU), plain or
+// upsample-scatter store.  T is the storage type of `res` / `out`.
+template <typename T, int TM, int TN, int UPS>
+__device__ __forceinline__ void conv_epilogue(const ConvK &p, f32x4 (&acc)[TM][TN], int row0,
+                                              int col0) {
+  // `res` may alias `out` (in-place accumulation of the fuse layers), so a residual load may
+  // not be scheduled across an earlier store by the compiler: issue ALL residual loads of a
+  // group first, then all stores.
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col0 + j * 16;
+    const float bias = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] += bias;
+  }
+  if constexpr (UPS == 1) {
+    if (p.res) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = col0 + j * 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = row0 + i * 16 + r;
+            if (col < p.Cout && row < p.M)
+              acc[i][j][r] += T::load(p.res, (long)row * p.res_ld + p.res_coff + col);
+          }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = col0 + j * 16;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + i * 16 + r;
+          if (col < p.Cout && row < p.M) {
+            const float o = p.relu ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
+            T::store(p.out, (long)row * p.out_ld + p.out_coff + col, o);
+          }
+        }
+    }
+  } else {
+    // conv1x1 + BN + nearest Upsample(UPS) + add (+ ReLU): every computed value goes to a
+    // UPS x UPS block of output pixels; residual loads are batched RG rows at a time
+    constexpr int RG = UPS >= 4 ? 16 / UPS : UPS;     // UPS 2 -> 2, 4 -> 4, 8 -> 2 rows
+    const int WoU = p.Wo * UPS;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + i * 16 + r;
+        if (row >= p.M) continue;
+        const int wo = row % p.Wo;
+        const int tq = row / p.Wo;
+        const int ho = tq % p.Ho;
+        const int b = tq / p.Ho;
+        const long pix0 = ((long)(b * p.Ho + ho) * UPS) * WoU + (long)wo * UPS;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = col0 + j * 16;
+          if (col >= p.Cout) continue;
+          const float v = acc[i][j][r];
+          const long rbase = pix0 * p.res_ld + p.res_coff + col;
+          const long obase = pix0 * p.out_ld + p.out_coff + col;
+#pragma unroll
+          for (int dy0 = 0; dy0 < UPS; dy0 += RG) {
+            float tmp[RG * UPS];
+#pragma unroll
+            for (int q = 0; q < RG * UPS; ++q)
+              tmp[q] = p.res ? T::load(p.res, rbase + ((long)(dy0 + q / UPS) * WoU + q % UPS) * p.res_ld)
+                             : 0.f;
+#pragma unroll
+            for (int q = 0; q < RG * UPS; ++q) {
+              const float o = v + tmp[q];
+              T::store(p.out, obase + ((long)(dy0 + q / UPS) * WoU + q % UPS) * p.out_ld,
+                       p.relu ? fmaxf(o, 0.f) : o);
+            }
+          }
+        }
+      }
+  }
+}
+
+}  // namespace shapy

@@ -18,44 +18,9 @@
 // LDS rows are unpadded; slot s of row r holds k-group s ^ f(r), f(r) = (r ^ (r >> 1)) & (KQ-1),
 // which makes both the staging writes and the fragment reads bank-conflict free
 // (tools/lds_swizzle_check.py checks the gfx950 lane-group table exhaustively).
-#include "common.h"
+#include "conv_common.h"
 
 namespace shapy {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct F32 {
-  using elem = float;
-  static constexpr int EPS = 4;       // elements per 16-byte slot
-  static __device__ __forceinline__ float load(const void *p, long i) {
-    return reinterpret_cast<const float *>(p)[i];
-  }
-  static __device__ __forceinline__ void store(void *p, long i, float v) {
-    reinterpret_cast<float *>(p)[i] = v;
-  }
-};
-
-struct BF16 {
-  using elem = unsigned short;
-  static constexpr int EPS = 8;
-  static __device__ __forceinline__ float load(const void *p, long i) {
-    return __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(p)[i] << 16);
-  }
-  static __device__ __forceinline__ void store(void *p, long i, float v) {
-    unsigned u = __float_as_uint(v);
-    u += 0x7fffu + ((u >> 16) & 1u);                    // round to nearest even
-    reinterpret_cast<unsigned short *>(p)[i] = (unsigned short)(u >> 16);
-  }
-};
-
-struct ConvK {
-  const void *in, *wgt, *res;
-  const float *bias;
-  void *out;
-  int M, Hi, Wi, Cin, in_ld, Ho, Wo, Cout, ks, stride, pad;
-  int out_ld, out_coff, res_ld, res_coff, relu, ups, swz, nbx, nby;
-  unsigned in_bytes, wgt_bytes;
-};
 
 template <typename T, int BM, int BN, int WM, int WN, int UPS, int KQ>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
@@ -72,15 +37,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  // workgroup -> tile.  Workgroup ids are dealt round-robin to the 8 XCDs (private L2s): with
-  // swz every XCD gets a CONTIGUOUS run of tiles (n fastest, then m), so the tiles that share
-  // A rows -- the N tiles of one M tile and the 3x3 halos of neighbouring M tiles -- hit the
-  // same L2.  Speed only; correctness does not depend on the placement.
-  int wg = blockIdx.x;
-  if (p.swz) {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-  }
+  const int wg = conv_tile_index(p);
   const int m_blk = (wg / p.nbx) * BM, n_blk = (wg % p.nbx) * BN;
   const int kq = t % KQ, lrow = t / KQ;
 
@@ -215,91 +172,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     __syncthreads();
   }
 
-  // ---- epilogue: bias (+ residual) (+ ReLU), plain or upsample-scatter store ----
-  // `res` may alias `out` (in-place accumulation of the fuse layers), so a residual load may
-  // not be scheduled across an earlier store by the compiler: issue ALL residual loads of a
-  // group first, then all stores.
   const int col_l = lane & 15, row_l = (lane >> 4) * 4;
-  const int row0 = m_blk + wm * (BM / WM) + row_l;
-  const int col0 = n_blk + wn * (BN / WN) + col_l;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = col0 + j * 16;
-    const float bias = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] += bias;
-  }
-  if constexpr (UPS == 1) {
-    if (p.res) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = col0 + j * 16;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = row0 + i * 16 + r;
-            if (col < p.Cout && row < p.M)
-              acc[i][j][r] += T::load(p.res, (long)row * p.res_ld + p.res_coff + col);
-          }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = col0 + j * 16;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = row0 + i * 16 + r;
-          if (col < p.Cout && row < p.M) {
-            const float o = p.relu ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
-            T::store(p.out, (long)row * p.out_ld + p.out_coff + col, o);
-          }
-        }
-    }
-  } else {
-    // conv1x1 + BN + nearest Upsample(UPS) + add (+ ReLU): every computed value goes to a
-    // UPS x UPS block of output pixels; residual loads are batched RG rows at a time
-    constexpr int RG = UPS >= 4 ? 16 / UPS : UPS;     // UPS 2 -> 2, 4 -> 4, 8 -> 2 rows
-    const int WoU = p.Wo * UPS;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = row0 + i * 16 + r;
-        if (row >= p.M) continue;
-        const int wo = row % p.Wo;
-        const int tq = row / p.Wo;
-        const int ho = tq % p.Ho;
-        const int b = tq / p.Ho;
-        const long pix0 = ((long)(b * p.Ho + ho) * UPS) * WoU + (long)wo * UPS;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = col0 + j * 16;
-          if (col >= p.Cout) continue;
-          const float v = acc[i][j][r];
-          const long rbase = pix0 * p.res_ld + p.res_coff + col;
-          const long obase = pix0 * p.out_ld + p.out_coff + col;
-#pragma unroll
-          for (int dy0 = 0; dy0 < UPS; dy0 += RG) {
-            float tmp[RG * UPS];
-#pragma unroll
-            for (int q = 0; q < RG * UPS; ++q)
-              tmp[q] = p.res ? T::load(p.res, rbase + ((long)(dy0 + q / UPS) * WoU + q % UPS) * p.res_ld)
-                             : 0.f;
-#pragma unroll
-            for (int q = 0; q < RG * UPS; ++q) {
-              const float o = v + tmp[q];
-              T::store(p.out, obase + ((long)(dy0 + q / UPS) * WoU + q % UPS) * p.out_ld,
-                       p.relu ? fmaxf(o, 0.f) : o);
-            }
-          }
-        }
-      }
-  }
+  conv_epilogue<T, TM, TN, UPS>(p, acc, m_blk + wm * (BM / WM) + row_l,
+                                n_blk + wn * (BN / WN) + col_l);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int UPS = 1, int KQ = 4>
@@ -336,6 +211,17 @@ int conv_tile_auto(int M, int Cout) {
   return mt * (p64 / 64) >= 512 ? SHAPY_TILE_64x64 : SHAPY_TILE_64x48;
 }
 
+int conv_tile_auto_x6(int M, int Cout, int K) {
+  // bf16x6 kernel, measured on MI355X at B = 64 (profiles/conv_bench_r01f_f32x6.txt): N tile
+  // (48 / 64 / 96) with the least padding; on a tie the 96-wide tile (wave tile 32x48) wins
+  // while M keeps >= 196 M-tiles busy, the 48-wide one below that; deep-K wide layers of the
+  // head take 128x64.
+  const int p48 = (Cout + 47) / 48 * 48, p64 = (Cout + 63) / 64 * 64, p96 = (Cout + 95) / 96 * 96;
+  if (p64 < p48 && p64 <= p96) return (Cout >= 1024 && K >= 1024) ? SHAPY_TILE_128x64 : SHAPY_TILE_64x64;
+  if (p96 <= p48 && p96 <= p64 && M >= 8192) return SHAPY_TILE_64x96;
+  return p48 <= p64 ? SHAPY_TILE_64x48 : SHAPY_TILE_64x64;
+}
+
 template <typename T>
 static int dispatch(const ConvK &k, int tile, int kq, hipStream_t s) {
   switch (tile) {
@@ -354,10 +240,11 @@ static int dispatch(const ConvK &k, int tile, int kq, hipStream_t s) {
 }
 
 int conv2d(const ShapyConv &d, hipStream_t s) {
-  const bool bf16 = d.dtype == SHAPY_DTYPE_BF16;
-  if (d.dtype != SHAPY_DTYPE_F32 && !bf16) return SHAPY_EINVAL;
+  const bool bf16 = d.dtype == SHAPY_DTYPE_BF16, x6 = d.dtype == SHAPY_DTYPE_F32X6;
+  if (d.dtype != SHAPY_DTYPE_F32 && !bf16 && !x6) return SHAPY_EINVAL;
   const int esz = bf16 ? 2 : 4, eps = 16 / esz;          // element size, elements per slot
-  if (d.Cin <= 0 || d.Cin % (4 * eps) || d.in_ld % eps || d.ksize < 1 || d.stride < 1 || d.ups < 1)
+  if (d.Cin <= 0 || d.Cin % (x6 ? 4 : 4 * eps) || d.in_ld % eps || d.ksize < 1 || d.stride < 1 ||
+      d.ups < 1)
     return SHAPY_EINVAL;
   if (((uintptr_t)d.in | (uintptr_t)d.wgt) & 15) return SHAPY_EINVAL;
   ConvK k;
@@ -382,9 +269,11 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   int kq = (Kc >= 128 * eps && k.Cin % (8 * eps) == 0) ? 8 : 4;
   if ((d.tile & 0x200) && k.Cin % (8 * eps) == 0) kq = 8;
   if (d.tile & 0x800) kq = 4;
-  int tile = (d.tile & 0xff) ? (d.tile & 0xff) : conv_tile_auto(k.M, k.Cout);
+  int tile = (d.tile & 0xff) ? (d.tile & 0xff)
+                             : (x6 ? conv_tile_auto_x6(k.M, k.Cout, Kc) : conv_tile_auto(k.M, k.Cout));
   if (k.ups != 1 && tile != SHAPY_TILE_64x48 && tile != SHAPY_TILE_64x64)
     tile = (k.Cout % 64 == 0 && k.Cout % 48 != 0) ? SHAPY_TILE_64x64 : SHAPY_TILE_64x48;
+  if (x6) return conv2d_x6(k, tile, s);
   return bf16 ? dispatch<BF16>(k, tile, kq, s) : dispatch<F32>(k, tile, kq, s);
 }
 

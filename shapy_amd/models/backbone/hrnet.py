@@ -317,7 +317,9 @@ class HighResolutionNet(nn.Module):
         self.multi_stream = True
         self.tile_overrides = {}
         self.tile_flags = 0          # OR-ed into every conv's tile id (tuning knobs)
-        #: 'f32' = exact-f32 MFMA (parity path); 'bf16' = bf16 weights/activations, f32 accumulate
+        #: 'f32' = exact-f32 MFMA (parity path); 'f32x6' = float32 storage, products from the
+        #: exact 3-way bf16 split on the bf16 matrix cores (float32-class accuracy);
+        #: 'bf16' = bf16 weights/activations, f32 accumulate
         self.compute_dtype = 'f32'
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
 
@@ -600,8 +602,10 @@ class HighResolutionNet(nn.Module):
         return P
 
     def _compile(self, H, W, device):
+        if self.compute_dtype not in ('f32', 'f32x6', 'bf16'):
+            raise ValueError(f'unknown compute_dtype {self.compute_dtype!r}')
         bf16 = self.compute_dtype == 'bf16'
-        key = (H, W, str(device), bf16)
+        key = (H, W, str(device), self.compute_dtype)
         eng = self._engine.get(key)
         if eng is not None:
             return eng
@@ -622,7 +626,8 @@ class HighResolutionNet(nn.Module):
         weights = torch.from_numpy(blob.copy()).to(device)
         eng = dict(ops=arr, n_ops=n, weights=weights, ws_per_img=ws_per_img, plan=P, ws=None,
                    feat_dim=P.ops[-1]['Cin'], esz=2 if bf16 else 4,
-                   dtype=_lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32)
+                   dtype={'f32': _lib.DTYPE_F32, 'bf16': _lib.DTYPE_BF16,
+                          'f32x6': _lib.DTYPE_F32X6}[self.compute_dtype])
         self._engine[key] = eng
         return eng
 

@@ -32,7 +32,7 @@ def lib():
 
 
 def _conv_call(lib, x, w, b, res=None, relu=False, stride=1, pad=0, ups=1, tile=0, out=None,
-               out_ld=None, out_coff=0):
+               out_ld=None, out_coff=0, x6=False):
     """x [B,H,W,C] NHWC cuda, w [O,kh,kw,C] cuda -> out NHWC."""
     from shapy_amd import _lib
     B, Hi, Wi, C = x.shape
@@ -43,6 +43,8 @@ def _conv_call(lib, x, w, b, res=None, relu=False, stride=1, pad=0, ups=1, tile=
         out = torch.empty(B, Ho * ups, Wo * ups, O, device=x.device, dtype=x.dtype)
     d = _lib.ShapyConv()
     d.dtype = _lib.DTYPE_BF16 if x.dtype == torch.bfloat16 else _lib.DTYPE_F32
+    if x6:
+        d.dtype = _lib.DTYPE_F32X6
     d.in_ = x.data_ptr(); d.wgt = w.data_ptr(); d.bias = b.data_ptr() if b is not None else None
     d.res = res.data_ptr() if res is not None else None
     d.out = out.data_ptr()
@@ -110,6 +112,57 @@ def test_conv_kernel_vs_float64(lib, case):
     ref = _conv_ref(x, w, b, res, relu, stride, pad, ups)
     err = (out.cpu().double() - ref).abs().max().item()
     assert err < 2e-5, err
+
+
+X6_CASES = [c for c in CONV_CASES if c[10] in (0, 5, 8, 2, 6, 3, 7)] + [
+    (2, 12, 12, 48, 48, 3, 1, 1, True, True, 8),      # Cin = 48: K chunks straddle taps
+    (2, 9, 11, 20, 70, 3, 1, 1, False, False, 0),     # Cin % 32 != 0, Cin < 32, N tail
+    (1, 8, 8, 4, 16, 1, 1, 1, False, False, 0),       # a single 4-wide K chunk
+    (2, 12, 12, 48, 96, 3, 2, 1, False, True, 9),     # 128x48, stride 2
+    (2, 12, 12, 64, 64, 3, 1, 1, True, True, 10),     # 128x64
+]
+
+
+@pytest.mark.parametrize('case', X6_CASES, ids=[str(c) for c in X6_CASES])
+def test_conv_kernel_f32x6_vs_float64(lib, case):
+    """float32 storage, products from the exact 3-way bf16 split (6 bf16 MFMAs, f32
+    accumulation): same tolerance as the native f32 kernel, and the two must agree to a few
+    float32 ulps of the accumulated magnitude."""
+    B, H, W, Cin, Cout, ks, stride, ups, use_res, relu, tile = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, ks, ks, Cin, generator=g) / np.sqrt(ks * ks * Cin)).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    pad = ks // 2
+    Ho = (H + 2 * pad - ks) // stride + 1
+    Wo = (W + 2 * pad - ks) // stride + 1
+    res = torch.randn(B, Ho * ups, Wo * ups, Cout, generator=g).cuda() if use_res else None
+    out = _conv_call(lib, x, w, b, res, relu, stride, pad, ups, tile, x6=True)
+    ref = _conv_ref(x, w, b, res, relu, stride, pad, ups)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5, err
+    if Cin % 16 == 0:                                  # the native f32 kernel needs Cin % 16 == 0
+        nat = _conv_call(lib, x, w, b, res, relu, stride, pad, ups, 0)
+        assert (out - nat).abs().max().item() < 1e-5
+
+
+def test_conv_f32x6_special_values(lib):
+    """The split is exact for every float32 whose third part stays a normal number
+    (|a| > 2^-102): huge and tiny operands, exact zeros and negative zero go through
+    unchanged in value."""
+    x = torch.zeros(1, 4, 4, 32)
+    vals = torch.tensor([3.0e38, -1.5e-30, 1e-30, 65504.0, -0.0, 1.0 + 2.0 ** -23, 123456.789,
+                         -7.0e-20])
+    x.view(-1)[:8] = vals
+    w = torch.zeros(16, 1, 1, 32)
+    for o in range(8):
+        w[o, 0, 0, o] = 1.0                           # output o copies input channel o
+    w[8, 0, 0, 5] = 1.0 - 2.0 ** -24
+    w[8, 0, 0, 6] = 2.0 ** -60
+    out = _conv_call(lib, x.cuda(), w.cuda(), None, x6=True)
+    assert torch.equal(out[0, 0, 0, :8].cpu(), vals)
+    want = (vals[5].double() * w[8, 0, 0, 5].double() + vals[6].double() * w[8, 0, 0, 6].double())
+    assert abs(out[0, 0, 0, 8].item() - want.item()) < 2.0 ** -23
 
 
 BF16_CASES = [
@@ -189,16 +242,23 @@ def network():
 
 @pytest.mark.parametrize('tag,b,s', [('b2_64', 2, 64), ('b3_96', 3, 96), ('b1_224', 1, 224)])
 @pytest.mark.parametrize('multi_stream', [False, True])
-def test_hrnet_features_vs_reference_golden(network, golden_dir, tag, b, s, multi_stream):
+@pytest.mark.parametrize('cdt', ['f32', 'f32x6'])
+def test_hrnet_features_vs_reference_golden(network, golden_dir, tag, b, s, multi_stream, cdt):
+    """Both float32 arithmetic paths (native f32 MFMA, bf16x6 split) against the reference's
+    CPU features at the north-star tolerance 1e-4."""
     from shapy_amd.utils import synthetic as syn
     g = np.load(osp.join(golden_dir, 'hrnet_golden.npz'))
     x = torch.from_numpy(syn.synthetic_images(b, s, 0)).cuda()
     network.backbone.multi_stream = multi_stream
-    with torch.no_grad():
-        feat = network.backbone(x)['concat']
-    torch.cuda.synchronize()
+    network.backbone.compute_dtype = cdt
+    try:
+        with torch.no_grad():
+            feat = network.backbone(x)['concat']
+        torch.cuda.synchronize()
+    finally:
+        network.backbone.compute_dtype = 'f32'
     err = np.abs(feat.cpu().numpy() - g[tag]).max()
-    print(tag, 'multi_stream', multi_stream, 'max abs err', err, 'scale', np.abs(g[tag]).max())
+    print(tag, cdt, 'multi_stream', multi_stream, 'max abs err', err, 'scale', np.abs(g[tag]).max())
     assert err < 1e-4, err
 
 
@@ -223,14 +283,19 @@ def test_hrnet_bf16_features_vs_f32_golden(network, golden_dir, tag, b, s):
     assert rel < 0.05, rel
 
 
-def test_full_forward_vs_reference_golden(network, golden_dir):
+@pytest.mark.parametrize('cdt', ['f32', 'f32x6'])
+def test_full_forward_vs_reference_golden(network, golden_dir, cdt):
     from shapy_amd.utils import synthetic as syn
     g = np.load(osp.join(golden_dir, 'regressor_golden.npz'))
     x = torch.from_numpy(syn.synthetic_images(4, 224, 0)).cuda()
     network.backbone.multi_stream = True
-    with torch.no_grad():
-        out = network(x, None)
-    torch.cuda.synchronize()
+    network.backbone.compute_dtype = cdt
+    try:
+        with torch.no_grad():
+            out = network(x, None)
+        torch.cuda.synchronize()
+    finally:
+        network.backbone.compute_dtype = 'f32'
     assert sorted(str(k) for k in out.keys()) == list(g['out_keys'])
     st = out['stage_02']
     assert sorted(st.keys()) == list(g['stage_keys'])

@@ -30,7 +30,7 @@ def main():
     ap.add_argument('--iters', type=int, default=8)
     ap.add_argument('--out', default='')
     ap.add_argument('--filter', default='', help='Hi,Cin,Cout,ksize: run only this class')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f32x6'])
     args = ap.parse_args()
     lib = _lib.load()
     net = HighResolutionNet(default_config().network.smplx.backbone.hrnet)
@@ -70,7 +70,7 @@ def main():
             d.ksize, d.stride, d.pad = ks, st, pad
             d.out_ld = Cout; d.out_coff = 0; d.res_ld = Cout if has_res else 0; d.res_coff = 0
             d.relu = int(relu); d.ups = ups; d.tile = _lib.TILES[tile]
-            d.dtype = _lib.DTYPE_BF16 if bf16 else _lib.DTYPE_F32
+            d.dtype = {'f32': _lib.DTYPE_F32, 'bf16': _lib.DTYPE_BF16, 'f32x6': _lib.DTYPE_F32X6}[args.dtype]
             for _ in range(2):
                 rc = lib.shapy_conv2d(ctypes.byref(d), stream)
                 assert rc == 0, (rc, key, tile)
