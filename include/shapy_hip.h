@@ -63,7 +63,9 @@ const char *shapy_build_arch(void);
 /* F32X6: float32 storage everywhere (same tensors as F32), products formed on the bf16 matrix
  * cores from the exact 3-way bf16 split of both operands (6 MFMAs per product, f32
  * accumulation; csrc/conv_x6.hip) -- float32-class accuracy, Cin only needs to be a multiple
- * of 4. */
+ * of 4.  In this mode ShapyConv.wgt holds the weights already split: bfloat16
+ * [Cout][3][Kp], planes (h, m, l) with h + m + l == w exactly, K = ksize*ksize*Cin zero-padded
+ * to Kp = a multiple of 32 (shapy_amd/utils/split.py:split_bf16x3). */
 enum { SHAPY_DTYPE_F32 = 0, SHAPY_DTYPE_BF16 = 1, SHAPY_DTYPE_F32X6 = 2 };
 
 typedef struct ShapyConv {

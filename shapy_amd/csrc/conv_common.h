@@ -37,6 +37,7 @@ struct ConvK {
   int M, Hi, Wi, Cin, in_ld, Ho, Wo, Cout, ks, stride, pad;
   int out_ld, out_coff, res_ld, res_coff, relu, ups, swz, nbx, nby;
   unsigned in_bytes, wgt_bytes;
+  int Kp;                       // bf16x6 weights: K rounded up to 32 (row length of a plane)
 };
 
 // float32 storage, bf16x6 split arithmetic on the bf16 matrix cores (conv_x6.hip)

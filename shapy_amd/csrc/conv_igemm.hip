@@ -255,7 +255,9 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   k.out_ld = d.out_ld; k.out_coff = d.out_coff; k.res_ld = d.res_ld; k.res_coff = d.res_coff;
   k.relu = d.relu; k.ups = d.ups;
   const unsigned long long in_bytes = (unsigned long long)esz * d.B * d.Hi * d.Wi * d.in_ld;
-  const unsigned long long wgt_bytes = (unsigned long long)esz * d.Cout * d.ksize * d.ksize * d.Cin;
+  k.Kp = (d.ksize * d.ksize * d.Cin + 31) / 32 * 32;
+  const unsigned long long wgt_bytes =
+      x6 ? 6ull * d.Cout * k.Kp : (unsigned long long)esz * d.Cout * d.ksize * d.ksize * d.Cin;
   if (in_bytes >= 0x7fffffffull || wgt_bytes >= 0x7fffffffull) return SHAPY_EINVAL;   // 32-bit offsets
   k.in_bytes = (unsigned)in_bytes; k.wgt_bytes = (unsigned)wgt_bytes;
   if (k.M <= 0 || k.Cout <= 0) return SHAPY_OK;

@@ -9,8 +9,10 @@
 // and six bf16 MFMAs reproduce the f32 product to the last f32 bit or so -- the dropped terms
 // are of the size of ONE f32 rounding of the product, the same error class the f32 MFMA chain
 // has -- for 6/16 of the matrix-core time.  Storage stays float32 everywhere (activations,
-// weights, residuals, outputs): the split happens in registers between the global load and the
-// LDS write, so this kernel is a drop-in for conv_igemm_kernel<F32>.
+// residuals, outputs): the activations are split in registers between the global load and the
+// LDS write; the weights are split ONCE on the host (shapy_amd/utils/split.py) and arrive as
+// three bf16 planes  [Cout][3][Kp]  (Kp = K rounded up to 32, zero padded), so their staging
+// is a plain 16-byte copy.
 //
 // Data flow per 32-wide K chunk: buffer_load_dwordx4 (4 consecutive k of one row) -> split
 // into 3 x 4 bf16 -> ds_write_b64 into three LDS planes (row = 32 bf16 = 64 B, 16-byte slots
@@ -26,15 +28,23 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned x1, unsigned x0) {
   return __builtin_amdgcn_perm(x1, x0, 0x07060302u);     // (x1 & 0xffff0000) | (x0 >> 16)
 }
 
-// 4 f32 -> three planes of 4 bf16 (8 bytes each); h + m + l == a exactly
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// 4 f32 -> three planes of 4 bf16 (8 bytes each); h + m + l == a exactly.  The subtractions
+// are written on float2 so that they become v_pk_add_f32 (two lanes of data per instruction).
 __device__ __forceinline__ void split3(const u32x4 &a, uint2 &h, uint2 &m, uint2 &l) {
   unsigned r1[4], r2[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float x = __uint_as_float(a[e]);
-    const float d1 = x - __uint_as_float(a[e] & 0xffff0000u);
-    r1[e] = __float_as_uint(d1);
-    r2[e] = __float_as_uint(d1 - __uint_as_float(r1[e] & 0xffff0000u));
+  for (int e = 0; e < 4; e += 2) {
+    const f32x2 x = {__uint_as_float(a[e]), __uint_as_float(a[e + 1])};
+    const f32x2 xh = {__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(a[e + 1] & 0xffff0000u)};
+    const f32x2 d1 = x - xh;
+    r1[e] = __float_as_uint(d1[0]);
+    r1[e + 1] = __float_as_uint(d1[1]);
+    const f32x2 dm = {__uint_as_float(r1[e] & 0xffff0000u), __uint_as_float(r1[e + 1] & 0xffff0000u)};
+    const f32x2 d2 = d1 - dm;
+    r2[e] = __float_as_uint(d2[0]);
+    r2[e + 1] = __float_as_uint(d2[1]);
   }
   h = make_uint2(pack_hi16(a[1], a[0]), pack_hi16(a[3], a[2]));
   m = make_uint2(pack_hi16(r1[1], r1[0]), pack_hi16(r1[3], r1[2]));
@@ -48,7 +58,8 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
   constexpr int ROWB = 64;                       // bytes per plane row: 32 bf16
   constexpr int PS = (BM + BN) * ROWB;           // plane stride
   constexpr int AR = BM / 32;                    // A rows staged per thread
-  constexpr int BR = (BN + 31) / 32;             // B rows staged per thread (guarded)
+  constexpr int BQ = 3 * BN;                     // B plane-rows per chunk
+  constexpr int BP = (BQ + 63) / 64;             // B plane-rows staged per thread (guarded)
   __shared__ __attribute__((aligned(16))) char lds[2][3 * PS];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -77,12 +88,16 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
     a_w[i] = wi0;
   }
   const int Kw = p.ks * p.ks * p.Cin;
-  int b_off[BR];
+  // B: plane-row q = plane * BN + row; 4 threads (16-byte slots) per plane-row of 32 bf16
+  const int bslot = t & 3;
+  int b_off[BP], b_st[BP];
 #pragma unroll
-  for (int i = 0; i < BR; ++i) {
-    const int r = lrow + 32 * i;
+  for (int i = 0; i < BP; ++i) {
+    const int q = (t >> 2) + 64 * i;
+    const int pl = q / BN, r = q - pl * BN;
     const int n = n_blk + r;
-    b_off[i] = ((r < BN) && (n < p.Cout)) ? n * Kw * 4 : OOB;
+    b_off[i] = (q < BQ && n < p.Cout) ? ((n * 3 + pl) * p.Kp + bslot * 8) * 2 : OOB;
+    b_st[i] = pl * PS + (BM + r) * ROWB + (((bslot ^ (r ^ (r >> 1))) & 3) << 4);
   }
 
   // this thread's position in the flattened K = (kh, kw, c) axis, for the NEXT chunk to fetch
@@ -96,7 +111,8 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
   wrap();
   const int n_chunks = (Kw + 31) / 32;
 
-  u32x4 a_reg[AR], b_reg[BR];
+  u32x4 a_reg[AR], b_reg[BP];
+  int kbyte = 0;                                 // byte offset of the next chunk in a weight row
   auto gload = [&]() {
     const bool valid = kflat < Kw;
     const int tap_in = ((kh * p.Wi + kw) * p.in_ld + c) * 4;
@@ -107,24 +123,23 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
       a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + tap_in : OOB, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < BR; ++i)
-      b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(
-          rs_w, (b_off[i] == OOB || !valid) ? OOB : b_off[i] + kflat * 4, 0, 0);
+    for (int i = 0; i < BP; ++i)
+      b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i], kbyte, 0);
+    kbyte += 64;
     kflat += 32;
     c += 32;
     wrap();
   };
 
   // staging writes: 8 bytes into slot (kq >> 1) ^ f(r) of row r, half kq & 1
-  int st_off[AR > BR ? AR : BR];
+  int st_off[AR];
 #pragma unroll
-  for (int i = 0; i < (AR > BR ? AR : BR); ++i) {
+  for (int i = 0; i < AR; ++i) {
     const int r = lrow + 32 * i;
     st_off[i] = r * ROWB + ((((kq >> 1) ^ (r ^ (r >> 1))) & 3) << 4) + ((kq & 1) << 3);
   }
   auto lstore = [&](int buf) {
     char *A = lds[buf];
-    char *Bt = lds[buf] + BM * ROWB;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       uint2 h, m, l;
@@ -134,14 +149,8 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
       *reinterpret_cast<uint2 *>(A + 2 * PS + st_off[i]) = l;
     }
 #pragma unroll
-    for (int i = 0; i < BR; ++i)
-      if (lrow + 32 * i < BN) {
-        uint2 h, m, l;
-        split3(b_reg[i], h, m, l);
-        *reinterpret_cast<uint2 *>(Bt + st_off[i]) = h;
-        *reinterpret_cast<uint2 *>(Bt + PS + st_off[i]) = m;
-        *reinterpret_cast<uint2 *>(Bt + 2 * PS + st_off[i]) = l;
-      }
+    for (int i = 0; i < BP; ++i)
+      if ((t >> 2) + 64 * i < BQ) *reinterpret_cast<u32x4 *>(lds[buf] + b_st[i]) = b_reg[i];
   };
 
   f32x4 acc[TM][TN];

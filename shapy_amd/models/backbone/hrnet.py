@@ -169,8 +169,9 @@ def _pack(items):
 class _Plan:
     """Flat op list + weight packing for one input resolution."""
 
-    def __init__(self, bf16=False):
+    def __init__(self, bf16=False, x6=False):
         self.bf16 = bf16
+        self.x6 = x6           # conv weights as three bf16 planes (utils/split.py), f32 otherwise
         self.ops = []          # dicts
         self.bufs = []
         self.wchunks = []      # byte strings, each padded to 16 bytes
@@ -200,6 +201,20 @@ class _Plan:
         else:
             raw, esz = t.numpy().tobytes(), 4
         off = self.wbytes // esz
+        raw += b'\0' * ((-len(raw)) % 16)
+        self.wchunks.append(raw)
+        self.wbytes += len(raw)
+        return off
+
+    def add_conv_weights(self, w):
+        """OHWI conv weights in the layout of the plan's arithmetic; offset in elements of the
+        activation type (float32 words for f32 / f32x6, bfloat16 for bf16)."""
+        if not self.x6:
+            return self.add_weights(w, as_bf16=self.bf16)
+        from ...utils.split import split_bf16x3
+        w = np.ascontiguousarray(w, np.float32)
+        raw = split_bf16x3(w.reshape(w.shape[0], -1)).tobytes()      # [Cout, 3, Kp] bf16
+        off = self.wbytes // 4
         raw += b'\0' * ((-len(raw)) % 16)
         self.wchunks.append(raw)
         self.wbytes += len(raw)
@@ -428,8 +443,8 @@ class HighResolutionNet(nn.Module):
         st['_engine'] = {}
         return st
 
-    def _build_plan(self, H, W, bf16=False):
-        P = _Plan(bf16)
+    def _build_plan(self, H, W, bf16=False, x6=False):
+        P = _Plan(bf16, x6)
         ov = self.tile_overrides
 
         def conv(conv_m, bn, inb, Hi, Wi, outb=None, res=None, relu=False, ups=1, lane=0,
@@ -453,7 +468,7 @@ class HighResolutionNet(nn.Module):
                  out_ld=out_ld or outb.C, out_coff=out_coff,
                  res_ld=(res_ld or (res.C if res is not None else 0)), res_coff=res_coff,
                  relu=int(relu), ups=ups, tile=_lib.TILES[ov.get(name, 'auto')] | self.tile_flags,
-                 wgt_off=P.add_weights(w, as_bf16=P.bf16), bias_off=P.add_weights(b))
+                 wgt_off=P.add_conv_weights(w), bias_off=P.add_weights(b))
             return outb, Ho, Wo
 
         # stem (hrnet.py:427-432)
@@ -609,7 +624,7 @@ class HighResolutionNet(nn.Module):
         eng = self._engine.get(key)
         if eng is not None:
             return eng
-        P = self._build_plan(H, W, bf16)
+        P = self._build_plan(H, W, bf16, self.compute_dtype == 'f32x6')
         ws_per_img = P.allocate()
         n = len(P.ops)
         arr = (_lib.ShapyOp * n)()

@@ -43,9 +43,12 @@ def _conv_call(lib, x, w, b, res=None, relu=False, stride=1, pad=0, ups=1, tile=
         out = torch.empty(B, Ho * ups, Wo * ups, O, device=x.device, dtype=x.dtype)
     d = _lib.ShapyConv()
     d.dtype = _lib.DTYPE_BF16 if x.dtype == torch.bfloat16 else _lib.DTYPE_F32
-    if x6:
+    wq = w
+    if x6:                                             # weights as three bf16 planes [O,3,Kp]
+        from shapy_amd.utils.split import split_bf16x3
         d.dtype = _lib.DTYPE_F32X6
-    d.in_ = x.data_ptr(); d.wgt = w.data_ptr(); d.bias = b.data_ptr() if b is not None else None
+        wq = torch.from_numpy(split_bf16x3(w.cpu().numpy().reshape(O, -1)).view(np.int16)).to(x.device)
+    d.in_ = x.data_ptr(); d.wgt = wq.data_ptr(); d.bias = b.data_ptr() if b is not None else None
     d.res = res.data_ptr() if res is not None else None
     d.out = out.data_ptr()
     d.B, d.Hi, d.Wi, d.Cin, d.in_ld = B, Hi, Wi, C, C

@@ -225,3 +225,16 @@ def test_dp_sharding_and_allgather_gloo():
         p.join(60)
     assert all(r[1] and r[2] for r in res), res
     assert sorted(r[3] for r in res) == [(0, 4), (4, 7)]
+
+
+def test_bf16x3_split_is_exact():
+    """utils/split.py: h + m + l == a bit for bit, planes zero-padded to a multiple of 32."""
+    from shapy_amd.utils.split import join_bf16x3, split_bf16x3
+    r = np.random.default_rng(0)
+    a = (r.standard_normal((5, 3, 48)) * np.exp(r.uniform(-20, 20, (5, 3, 48)))).astype(np.float32)
+    a[0, 0, :6] = [0.0, -0.0, 3.0e38, -1.5e-30, 1.0 + 2.0 ** -23, 65504.0]
+    planes = split_bf16x3(a)
+    assert planes.shape == (5, 3, 3, 64) and planes.dtype == np.uint16
+    assert not planes[..., 48:].any()
+    back = join_bf16x3(planes, 48)
+    assert np.array_equal(back, a)

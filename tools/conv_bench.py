@@ -56,6 +56,10 @@ def main():
         Ho, Wo = (Hi + 2 * pad - ks) // st + 1, (Wi + 2 * pad - ks) // st + 1
         x = torch.randn(B, Hi, Wi, Cin, device='cuda').to(tdt)
         w = (torch.randn(Cout, ks, ks, Cin, device='cuda') * 0.05).to(tdt)
+        if args.dtype == 'f32x6':                      # three bf16 planes [Cout, 3, Kp]
+            from shapy_amd.utils.split import split_bf16x3
+            import numpy as np
+            w = torch.from_numpy(split_bf16x3(w.cpu().numpy().reshape(Cout, -1)).view(np.int16)).cuda()
         b = torch.randn(Cout, device='cuda')
         out = torch.empty(B, Ho * ups, Wo * ups, Cout, device='cuda', dtype=tdt)
         res = torch.randn_like(out) if has_res else None
