@@ -89,6 +89,8 @@ def main():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--single-stream', action='store_true')
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
+                    help='replay the backbone as one hipGraph (auto: batches <= 8)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f32x6', 'bf16'],
                     help='f32 = BASELINE configs[1] (headline) on the f32 matrix-core path; '
                          'f32x6 = same float32 tensors, products from the exact 3-way bf16 split '
@@ -117,6 +119,7 @@ def main():
                              else '/tmp/shapy_synth_models')
     net.backbone.multi_stream = not args.single_stream
     net.backbone.compute_dtype = args.dtype
+    net.backbone.use_graph = {'auto': 'auto', 'on': True, 'off': False}[args.graph]
     B = args.batch
     # distinct synthetic images per rank (global batch = world * B), resident in HBM
     x = torch.from_numpy(syn.synthetic_images(B, args.size, 100 + rank)).cuda()
@@ -191,7 +194,10 @@ def main():
                                        'bf16': 'bf16 storage / f32 accumulate (BASELINE '
                                                'configs[2] precision)'}[args.dtype],
                        'global_batch': world * B, 'parallelism': f'dp{world}',
-                       'multi_stream': not args.single_stream},
+                       'multi_stream': not args.single_stream,
+                       'hip_graph': bool(net.backbone.use_graph is True or
+                                         (net.backbone.use_graph == 'auto' and
+                                          B <= net.backbone.graph_max_batch))},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': pmc_traffic(B, args.size) if args.dtype == 'f32' else None,

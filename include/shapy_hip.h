@@ -111,6 +111,19 @@ int shapy_hrnet_run(const ShapyOp *ops_host, int n_ops, const void *weights,
                     const float *input_nchw, void *workspace, int64_t ws_elems_per_image,
                     float *features_out, int B, int H, int W, int multi_stream, int dtype,
                     void *stream);
+
+/* The same forward captured once into a hipGraph (side-stream branches included) and replayed
+ * with one launch: removes the ~330 kernel launches + fork/join events per forward from the
+ * host, which dominate at small batch.  All pointers are baked into the graph: the caller
+ * keeps input / workspace / features_out / weights alive and at the same addresses for the
+ * life of the graph, copies new images into `input_nchw` before shapy_hrnet_graph_launch and
+ * reads `features_out` after it (stream-ordered).  ops_host is only read during create. */
+int shapy_hrnet_graph_create(const ShapyOp *ops_host, int n_ops, const void *weights,
+                             const float *input_nchw, void *workspace,
+                             int64_t ws_elems_per_image, float *features_out, int B, int H,
+                             int W, int multi_stream, int dtype, void **graph_out);
+int shapy_hrnet_graph_launch(void *graph, void *stream);
+int shapy_hrnet_graph_destroy(void *graph);
 /* dtype = SHAPY_DTYPE_F32: weights / workspace are float32 (the parity path);
  * SHAPY_DTYPE_BF16: conv weights and activations are bfloat16 (biases stay float32 and live in
  * the blob at 4-byte granularity: bias_off counts float32 elements, wgt_off bfloat16 elements),

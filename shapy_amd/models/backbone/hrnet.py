@@ -332,6 +332,11 @@ class HighResolutionNet(nn.Module):
         self.multi_stream = True
         self.tile_overrides = {}
         self.tile_flags = 0          # OR-ed into every conv's tile id (tuning knobs)
+        #: replay the forward as one hipGraph (csrc/capi.hip) instead of ~330 launches: True,
+        #: False, or 'auto' = for batches up to graph_max_batch, where the host launch cost
+        #: exceeds the GPU time
+        self.use_graph = 'auto'
+        self.graph_max_batch = 8
         #: 'f32' = exact-f32 MFMA (parity path); 'f32x6' = float32 storage, products from the
         #: exact 3-way bf16 split on the bf16 matrix cores (float32-class accuracy);
         #: 'bf16' = bf16 weights/activations, f32 accumulate
@@ -640,11 +645,20 @@ class HighResolutionNet(nn.Module):
         blob = np.frombuffer(b''.join(P.wchunks), dtype=np.uint8)
         weights = torch.from_numpy(blob.copy()).to(device)
         eng = dict(ops=arr, n_ops=n, weights=weights, ws_per_img=ws_per_img, plan=P, ws=None,
+                   graphs={},
                    feat_dim=P.ops[-1]['Cin'], esz=2 if bf16 else 4,
                    dtype={'f32': _lib.DTYPE_F32, 'bf16': _lib.DTYPE_BF16,
                           'f32x6': _lib.DTYPE_F32X6}[self.compute_dtype])
         self._engine[key] = eng
         return eng
+
+    def _forward_graph(self, lib, eng, x):
+        B, _, H, W = x.shape
+        key = (B, bool(self.multi_stream))
+        g = eng['graphs'].get(key)
+        if g is None:
+            g = eng['graphs'][key] = _CapturedForward(lib, eng, B, H, W, x.device, self.multi_stream)
+        return g(x)
 
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != 3:
@@ -656,6 +670,8 @@ class HighResolutionNet(nn.Module):
             raise ValueError('HRNet input height/width must be multiples of 32')
         x = x.contiguous().float()
         eng = self._compile(H, W, x.device)
+        if self.use_graph is True or (self.use_graph == 'auto' and B <= self.graph_max_batch):
+            return {'concat': self._forward_graph(lib, eng, x)}
         need = eng['ws_per_img'] * B * eng['esz']
         if eng['ws'] is None or eng['ws'].numel() < need:
             eng['ws'] = torch.empty(need, dtype=torch.uint8, device=x.device)
@@ -665,6 +681,39 @@ class HighResolutionNet(nn.Module):
                                  int(self.multi_stream), eng['dtype'], _lib.current_stream())
         _lib.check(rc, 'shapy_hrnet_run')
         return {'concat': feat}
+
+
+class _CapturedForward:
+    """One hipGraph of the whole backbone for a fixed batch size, with the buffers it has baked
+    in (they must stay alive and in place as long as the graph exists)."""
+
+    def __init__(self, lib, eng, B, H, W, device, multi_stream):
+        self.lib = lib
+        self.x = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
+        self.feat = torch.empty(B, eng['feat_dim'], dtype=torch.float32, device=device)
+        self.ws = torch.empty(eng['ws_per_img'] * B * eng['esz'], dtype=torch.uint8, device=device)
+        self.weights = eng['weights']
+        self.handle = ctypes.c_void_p()
+        # capture happens on a private stream inside the library; make the buffers visible to it
+        torch.cuda.current_stream().synchronize()
+        rc = lib.shapy_hrnet_graph_create(eng['ops'], eng['n_ops'], _lib.ptr(self.weights),
+                                          _lib.ptr(self.x), _lib.ptr(self.ws), eng['ws_per_img'],
+                                          _lib.ptr(self.feat), B, H, W, int(multi_stream),
+                                          eng['dtype'], ctypes.byref(self.handle))
+        _lib.check(rc, 'shapy_hrnet_graph_create')
+
+    def __call__(self, x):
+        self.x.copy_(x)
+        _lib.check(self.lib.shapy_hrnet_graph_launch(self.handle, _lib.current_stream()),
+                   'shapy_hrnet_graph_launch')
+        return self.feat.clone()          # the next replay overwrites the baked-in output
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.shapy_hrnet_graph_destroy(self.handle)
+        except Exception:                  # interpreter shutdown
+            pass
 
 
 def build(cfg, pretrained=True, **kwargs):

@@ -265,6 +265,35 @@ def test_hrnet_features_vs_reference_golden(network, golden_dir, tag, b, s, mult
     assert err < 1e-4, err
 
 
+@pytest.mark.parametrize('multi_stream', [False, True])
+def test_hrnet_graph_replay_equals_eager(network, multi_stream):
+    """The hipGraph replay (default for small batches) runs the same kernels on the same
+    buffers as the eager op list: bit-identical features, also on a second replay with new
+    images and after an eager call in between."""
+    from shapy_amd.utils import synthetic as syn
+    bb = network.backbone
+    bb.multi_stream = multi_stream
+    xs = [torch.from_numpy(syn.synthetic_images(3, 96, seed)).cuda() for seed in (5, 6)]
+    try:
+        bb.use_graph = False
+        with torch.no_grad():
+            eager = [bb(x)['concat'].clone() for x in xs]
+        bb.use_graph = True
+        with torch.no_grad():
+            g0 = bb(xs[0])['concat']
+            g1 = bb(xs[1])['concat']
+            bb.use_graph = False
+            e1 = bb(xs[1])['concat']
+            bb.use_graph = True
+            g0b = bb(xs[0])['concat']
+        torch.cuda.synchronize()
+    finally:
+        bb.use_graph = 'auto'
+    assert torch.equal(g0, eager[0]) and torch.equal(g1, eager[1])
+    assert torch.equal(e1, eager[1]) and torch.equal(g0b, eager[0])
+    assert g0.data_ptr() != g0b.data_ptr()               # outputs are copies, not the baked buffer
+
+
 @pytest.mark.parametrize('tag,b,s', [('b2_64', 2, 64), ('b1_224', 1, 224)])
 def test_hrnet_bf16_features_vs_f32_golden(network, golden_dir, tag, b, s):
     """BASELINE configs[2]: bf16 weights/activations, f32 accumulate.  It does not meet the 1e-4
