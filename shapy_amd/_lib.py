@@ -55,7 +55,7 @@ OP_CONV, OP_STEM, OP_MEANPOOL = 0, 1, 2
 POSE_ROTMAT, POSE_CONT6D, POSE_AXIS_ANGLE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F32X6 = 0, 1, 2
 TILES = {'auto': 0, '256x48': 1, '128x96': 2, '128x128': 3, '256x64': 4, '64x48': 5,
-         '64x96': 6, '64x128': 7, '64x64': 8, '128x48': 9, '128x64': 10}
+         '64x96': 6, '64x128': 7, '64x64': 8, '128x48': 9, '128x64': 10, '32x64': 11}
 for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: conv2d)
     TILES[_k + '+noswz'] = _v | 0x400
     TILES[_k + '+bk32'] = _v | 0x200

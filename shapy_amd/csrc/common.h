@@ -22,6 +22,7 @@ enum {
   SHAPY_TILE_64x64 = 8,
   SHAPY_TILE_128x48 = 9,
   SHAPY_TILE_128x64 = 10,
+  SHAPY_TILE_32x64 = 11,     // long K chunks only (Cin % 32 == 0); for layers with few M tiles
 };
 
 int conv2d(const ShapyConv &d, hipStream_t s);

@@ -235,6 +235,9 @@ static int dispatch(const ConvK &k, int tile, int kq, hipStream_t s) {
     case SHAPY_TILE_128x128: return launch<T, 128, 128, 2, 2>(k, s);
     case SHAPY_TILE_256x48: return launch<T, 256, 48, 4, 1>(k, s);
     case SHAPY_TILE_256x64: return launch<T, 256, 64, 4, 1>(k, s);
+    case SHAPY_TILE_32x64:
+      if (kq != 8 || k.ups != 1) return SHAPY_EINVAL;
+      return launch<T, 32, 64, 2, 2, 1, 8>(k, s);
     default: return SHAPY_EINVAL;
   }
 }
@@ -273,6 +276,10 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   if (d.tile & 0x800) kq = 4;
   int tile = (d.tile & 0xff) ? (d.tile & 0xff)
                              : (x6 ? conv_tile_auto_x6(k.M, k.Cout, Kc) : conv_tile_auto(k.M, k.Cout));
+  // few M tiles (14x14 / 7x7 maps at B = 64): halve BM so that every CU still holds several
+  // workgroups (+4..12 %, profiles/conv_bench_r01h_32x64.txt)
+  if (!(d.tile & 0xff) && !bf16 && !x6 && kq == 8 && k.ups == 1 && k.Cout % 64 == 0 && k.M <= 12544)
+    tile = SHAPY_TILE_32x64;
   if (k.ups != 1 && tile != SHAPY_TILE_64x48 && tile != SHAPY_TILE_64x64)
     tile = (k.Cout % 64 == 0 && k.Cout % 48 != 0) ? SHAPY_TILE_64x64 : SHAPY_TILE_64x48;
   if (x6) return conv2d_x6(k, tile, s);

@@ -97,6 +97,8 @@ CONV_CASES = [
     (2, 3, 3, 384, 48, 1, 1, 8, True, True, 5),       # fuse: x8
     (5, 1, 1, 496, 1000, 1, 1, 1, True, False, 0),    # GEMM with N tail, M tail
     (4, 1, 1, 32, 31425, 1, 1, 1, False, False, 0),   # blend-shape GEMM shape
+    (2, 7, 7, 192, 192, 3, 1, 1, True, True, 11),     # 32x64 (few M tiles), M tail
+    (1, 7, 7, 512, 2048, 1, 1, 1, True, True, 11),    # 32x64, 1x1
 ]
 
 
