@@ -171,6 +171,9 @@ def main():
               'bf16': 'conv_igemm_kernel<BF16> (v_mfma_f32_16x16x32_bf16)',
               'f32x6': 'conv_x6_kernel (6 x v_mfma_f32_16x16x32_bf16 per f32 product; peak = '
                        'dense bf16 peak / 6)'}[args.dtype]
+    # HBM bytes per launch group (one backbone forward) from the committed PMC passes, gfx950
+    # FETCH x2 correction applied; measured on the f32 build
+    traffic = pmc_traffic(B, args.size) if args.dtype == 'f32' else None
     if rank == 0:
         res = {
             'metric': 'images/sec whole-node (HRNet+SMPL-X fwd), 224x224 bs=64; betas L2 vs CPU',
@@ -200,7 +203,10 @@ def main():
                                           B <= net.backbone.graph_max_batch))},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': pmc_traffic(B, args.size) if args.dtype == 'f32' else None,
+                         'traffic': traffic['bytes_fetch_x2_corrected'] if traffic else None,
+                         'traffic_detail': traffic,
+                         'peak_sustained_measured': {'f32': 141.0, 'bf16': 1410.0,
+                                                     'f32x6': 1410.0 / 6.0}[args.dtype],
                          'kernel': kernel + ', 330 launches per backbone forward',
                          'flop_per_launch_group': flop_img * B,
                          'ms_per_launch_group': backbone_ms},
