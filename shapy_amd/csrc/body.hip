@@ -9,29 +9,53 @@ namespace shapy {
 // IterativeRegression (networks.py:536-592) with the affine-collapsed MLP:
 //   t = Wf feat + b ;  p_s = p_{s-1} + t + Wp p_{s-1}
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void regressor_affine_kernel(
-    const float *__restrict__ feat, const float *__restrict__ Wf, const float *__restrict__ Wp,
-    const float *__restrict__ bias, const float *__restrict__ mean, float *__restrict__ out, int B,
-    int F, int P, int S, int mean_stride) {
+// Phase 1: t[b][r] = Wf[r] . feat[b] + bias[r].  One wave per output row, RB bodies per
+// workgroup: a row of Wf (8 KB) is read once per RB bodies and the grid has P/4 x B/RB
+// workgroups instead of B (the one-workgroup-per-body version re-read the whole 1.2 MB of Wf for
+// every body and ran on 64 of 256 CUs: 196 us at B = 64).  Per (row, body) the summation order
+// is unchanged: lane l accumulates k = 4 l + 256 i in order, then a butterfly over the wave.
+constexpr int REG_RB = 8;
+__global__ __launch_bounds__(256) void regressor_feat_kernel(
+    const float *__restrict__ feat, const float *__restrict__ Wf, const float *__restrict__ bias,
+    float *__restrict__ t_out, int B, int F, int P) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave, b0 = blockIdx.y * REG_RB;
+  if (r >= P) return;
+  const float *w = Wf + (long)r * F;
+  float s[REG_RB];
+#pragma unroll
+  for (int j = 0; j < REG_RB; ++j) s[j] = 0.f;
+  for (int k = lane * 4; k < F; k += 256) {
+    const float4 wv = *reinterpret_cast<const float4 *>(w + k);
+#pragma unroll
+    for (int j = 0; j < REG_RB; ++j) {
+      const int b = b0 + j < B ? b0 + j : B - 1;
+      const float4 xv = *reinterpret_cast<const float4 *>(feat + (long)b * F + k);
+      s[j] = fmaf(wv.x, xv.x, s[j]); s[j] = fmaf(wv.y, xv.y, s[j]);
+      s[j] = fmaf(wv.z, xv.z, s[j]); s[j] = fmaf(wv.w, xv.w, s[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < REG_RB; ++j) {
+    const float v = wave_reduce_sum(s[j]);
+    if (lane == 0 && b0 + j < B) t_out[(long)(b0 + j) * P + r] = v + bias[r];
+  }
+}
+
+// Phase 2: the stages, p_s = p_{s-1} + t + Wp p_{s-1}; one workgroup per body.  t arrives in
+// the slot of the LAST stage of `out` and is copied to LDS before anything is written.
+__global__ __launch_bounds__(256) void regressor_stage_kernel(
+    const float *__restrict__ Wp, const float *__restrict__ mean, float *__restrict__ out, int B,
+    int P, int S, int mean_stride) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float *t = sm;            // [P]
   float *pa = sm + P;       // [P]
   float *pb = sm + 2 * P;   // [P]
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float *x = feat + (long)b * F;
-  for (int r = wave; r < P; r += 4) {
-    const float *w = Wf + (long)r * F;
-    float s = 0.f;
-    for (int k = lane * 4; k < F; k += 256) {
-      const float4 wv = *reinterpret_cast<const float4 *>(w + k);
-      const float4 xv = *reinterpret_cast<const float4 *>(x + k);
-      s = fmaf(wv.x, xv.x, s); s = fmaf(wv.y, xv.y, s);
-      s = fmaf(wv.z, xv.z, s); s = fmaf(wv.w, xv.w, s);
-    }
-    s = wave_reduce_sum(s);
-    if (lane == 0) t[r] = s + bias[r];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < P; i += 256) {
+    t[i] = out[((long)(S - 1) * B + b) * P + i];
+    pa[i] = mean[(long)b * mean_stride + i];
   }
-  for (int i = tid; i < P; i += 256) pa[i] = mean[(long)b * mean_stride + i];
   __syncthreads();
   float *prev = pa, *next = pb;
   for (int s = 0; s < S; ++s) {
@@ -384,9 +408,13 @@ extern "C" int shapy_regressor_affine_f32(const float *features, const float *Wf
                                           int cond_per_body, void *stream) {
   if (B <= 0) return SHAPY_OK;
   if ((F & 3) || P <= 0 || num_stages < 1) return SHAPY_EINVAL;
-  hipLaunchKernelGGL(regressor_affine_kernel, dim3(B), dim3(256), 3 * P * sizeof(float),
-                     (hipStream_t)stream, features, Wf, Wp, bias, mean_param, params_out, B, F, P,
-                     num_stages, cond_per_body ? P : 0);
+  float *t = params_out + (long)(num_stages - 1) * B * P;
+  hipLaunchKernelGGL(regressor_feat_kernel, dim3((P + 3) / 4, (B + REG_RB - 1) / REG_RB), dim3(256),
+                     0, (hipStream_t)stream, features, Wf, bias, t, B, F, P);
+  SHAPY_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(regressor_stage_kernel, dim3(B), dim3(256), 3 * P * sizeof(float),
+                     (hipStream_t)stream, Wp, mean_param, params_out, B, P, num_stages,
+                     cond_per_body ? P : 0);
   return (int)hipGetLastError();
 }
 
