@@ -75,7 +75,14 @@ def cpu_baseline(batch, size, budget_s=15.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {'value': n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+    cpu = ''
+    try:
+        with open('/proc/cpuinfo') as fh:
+            cpu = next((ln.split(':', 1)[1].strip() for ln in fh if ln.startswith('model name')), '')
+    except OSError:
+        pass
+    return {'value': n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port', 'cpu_model': cpu,
+            'host_logical_cpus': os.cpu_count(),
             'sample': f'{n} images ({size}x{size}, batches of {b}) through the CPU oracle '
                       f'(torch-CPU HRNet + numpy SMPL-X + C intersection + scipy hull) in {dt:.1f} s'}
 
