@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
   constexpr int AR = BM / 32;                    // A rows staged per thread
   constexpr int BQ = 3 * BN;                     // B plane-rows per chunk
   constexpr int BP = (BQ + 63) / 64;             // B plane-rows staged per thread (guarded)
-  __shared__ __attribute__((aligned(16))) char lds[2][3 * PS];
+  // ONE staging buffer and two barriers per chunk: barriers cost nothing measurable here,
+  // LDS footprint does (21.5 KB instead of 43 KB per workgroup doubles the workgroups per CU:
+  // +8.5 % end to end, profiles/r01_ablation_probes.txt)
+  __shared__ __attribute__((aligned(16))) char lds[3 * PS];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
     const int r = lrow + 32 * i;
     st_off[i] = r * ROWB + ((((kq >> 1) ^ (r ^ (r >> 1))) & 3) << 4) + ((kq & 1) << 3);
   }
-  auto lstore = [&](int buf) {
-    char *A = lds[buf];
+  auto lstore = [&]() {
+    char *A = lds;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       uint2 h, m, l;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i)
-      if ((t >> 2) + 64 * i < BQ) *reinterpret_cast<u32x4 *>(lds[buf] + b_st[i]) = b_reg[i];
+      if ((t >> 2) + 64 * i < BQ) *reinterpret_cast<u32x4 *>(lds + b_st[i]) = b_reg[i];
   };
 
   f32x4 acc[TM][TN];
@@ -166,14 +169,13 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
   const int b_base = BM * ROWB + wn * (BN / WN) * ROWB + frag_off;
 
   gload();
-  lstore(0);
+  lstore();
   __syncthreads();
 
   for (int kc = 0; kc < n_chunks; ++kc) {
-    const int cur = kc & 1;
     const bool more = kc + 1 < n_chunks;
     if (more) gload();
-    const char *L = lds[cur];
+    const char *L = lds;
     bf16x8 af[3][TM], bf[3][TN];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
@@ -196,7 +198,8 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA[q]][i], bf[PB[q]][j],
                                                               acc[i][j], 0, 0, 0);
-    if (more) lstore(cur ^ 1);
+    __syncthreads();                         // everybody is done reading the buffer
+    if (more) lstore();
     __syncthreads();
   }
 
