@@ -176,28 +176,30 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
     const bool more = kc + 1 < n_chunks;
     if (more) gload();
     const char *L = lds;
-    bf16x8 af[3][TM], bf[3][TN];
+    // Register budget decides the occupancy of this kernel: only the A fragments (3 planes) stay
+    // live; the B fragments are read one N tile at a time and consumed by the 6 x TM MFMAs of
+    // that tile (smallest terms first; with TM > 1 consecutive MFMAs alternate accumulators).
+    bf16x8 af[3][TM];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
         af[pl][i] = *reinterpret_cast<const bf16x8 *>(L + pl * PS + a_base + i * 16 * ROWB);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[pl][j] = *reinterpret_cast<const bf16x8 *>(L + pl * PS + b_base + j * 16 * ROWB);
-    }
-    // smallest terms first; the tile loops are innermost so that consecutive MFMAs hit
-    // different accumulators
     constexpr int PA[6] = {1, 2, 0, 1, 0, 0};   // mm, lh, hl, mh, hm, hh
     constexpr int PB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int j = 0; j < TN; ++j) {
+      bf16x8 bf[3];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int pl = 0; pl < 3; ++pl)
+        bf[pl] = *reinterpret_cast<const bf16x8 *>(L + pl * PS + b_base + j * 16 * ROWB);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA[q]][i], bf[PB[q]][j],
-                                                              acc[i][j], 0, 0, 0);
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA[q]][i], bf[PB[q]], acc[i][j],
+                                                              0, 0, 0);
+    }
     __syncthreads();                         // everybody is done reading the buffer
     if (more) lstore();
     __syncthreads();
