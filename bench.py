@@ -121,6 +121,11 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', init_method='env://')
+    if rank == 0 and not osp.exists(osp.join(ROOT, 'shapy_amd', 'csrc', 'libshapy_hip.so')):
+        from shapy_amd import build as hip_build      # fresh checkout: the library is git-ignored
+        hip_build.build()
+    if world > 1:
+        dist.barrier()
 
     net, _ = ge.make_network(model_folder=f'/tmp/shapy_synth_models_r{local_rank}' if world > 1
                              else '/tmp/shapy_synth_models')
