@@ -27,6 +27,20 @@
  *      BodyMeasurements.forward: compute_mass / compute_height / compute_peripheries incl.
  *      the per-mesh scipy ConvexHull (mesh-mesh-intersection/body_measurements/
  *      body_measurements.py:99-246)
+ *  shapy_hrnet_graph_create / _launch / _destroy
+ *      the same forward as shapy_hrnet_run, captured once into a hipGraph (no reference
+ *      counterpart: the reference launches every cuDNN call from Python)
+ *  shapy_pose_decode_f32, shapy_weak_persp_project_f32, shapy_joint_regress_f32
+ *      the decoders / camera / extra-joint regressors used stand-alone by the host mirror
+ *      (pose_utils.py:84-153, camera_projection.py:181-213, body_models.py:738-744)
+ *  shapy_b2a_polynomial_f32
+ *      B2A / Polynomial.forward (attributes/attributes/attributes_betas/polynomial.py:61-69,137-140)
+ *  shapy_crop_resize_normalize_u8
+ *      the CPU crop + resize + normalise of the OpenPose dataset
+ *      (regressor/human_shape/data/datasets/openpose.py:146-246, utils/transf_utils.py:53-96)
+ *  shapy_aligned_point_error_f32, shapy_p2p_error_f64
+ *      PointError / the alignments / v2vhdError of the evaluator
+ *      (regressor/human_shape/utils/metrics.py:31-56,84-277,335-460)
  */
 #ifndef SHAPY_HIP_H
 #define SHAPY_HIP_H
