@@ -38,6 +38,7 @@ struct ConvK {
   int out_ld, out_coff, res_ld, res_coff, relu, ups, swz, nbx, nby;
   unsigned in_bytes, wgt_bytes;
   int Kp;                       // bf16x6 weights: K rounded up to 32 (row length of a plane)
+  int vec4;                     // float32 out / res rows are 16-byte aligned: vector epilogue
 };
 
 // float32 storage, bf16x6 split arithmetic on the bf16 matrix cores (conv_x6.hip)
@@ -142,6 +143,60 @@ __device__ __forceinline__ void conv_epilogue(const ConvK &p, f32x4 (&acc)[TM][T
           }
         }
       }
+  }
+}
+
+// LDS bytes a workgroup needs for conv_epilogue_vec (4 waves, wave tile 16 TM x 16 TN)
+constexpr int conv_epilogue_vec_bytes(int TM, int TN) { return 4 * (16 * TM) * (16 * TN + 4) * 4; }
+
+// float32 epilogue with full-line stores.  The MFMA C layout gives a lane one column and four
+// rows, i.e. a wave store instruction writes 64-byte row segments; here every wave first parks
+// its (bias-added) tile in a private LDS region and reads it back row-major, so that residual
+// loads and stores are 16 bytes per lane over whole 128..256-byte row segments.  No workgroup
+// barrier: a wave only reads what it wrote itself (the staging buffer is free after the K loop).
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_vec(const ConvK &p, f32x4 (&acc)[TM][TN],
+                                                  char *lds_wave, int row0, int col0, int lane) {
+  constexpr int R = 16 * TM, C = 16 * TN, LDC = C + 4, C4 = C / 4;
+  float *s = reinterpret_cast<float *>(lds_wave);
+  const int cl = lane & 15, rl = (lane >> 4) * 4;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col0 + j * 16 + cl;
+    const float bias = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[(i * 16 + rl + r) * LDC + j * 16 + cl] = acc[i][j][r] + bias;
+  }
+  // the tile is read back by other lanes of the same wave: LDS executes a wave's instructions
+  // in order; the asm keeps the compiler from moving the reads above the writes
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const float *res = reinterpret_cast<const float *>(p.res);
+  float *out = reinterpret_cast<float *>(p.out);
+#pragma unroll
+  for (int q0 = 0; q0 < R * C4; q0 += 64) {
+    const int q = q0 + lane;
+    if ((R * C4) % 64 != 0 && q >= R * C4) break;
+    const int rr = q / C4, c4 = q % C4;
+    const int row = row0 + rr, col = col0 + c4 * 4;
+    if (row >= p.M || col >= p.Cout) continue;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(s + rr * LDC + c4 * 4);
+    float *o = out + (long)row * p.out_ld + p.out_coff + col;
+    const float *rp = res ? res + (long)row * p.res_ld + p.res_coff + col : nullptr;
+    if (col + 3 < p.Cout) {
+      if (rp) v += *reinterpret_cast<const f32x4 *>(rp);
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      *reinterpret_cast<f32x4 *>(o) = v;
+    } else {
+      for (int e = 0; e < 4 && col + e < p.Cout; ++e) {
+        const float x = v[e] + (rp ? rp[e] : 0.f);
+        o[e] = p.relu ? fmaxf(x, 0.f) : x;
+      }
+    }
   }
 }
 
