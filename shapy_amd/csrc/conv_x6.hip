@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
   // ONE staging buffer and two barriers per chunk: barriers cost nothing measurable here,
   // LDS footprint does (21.5 KB instead of 43 KB per workgroup doubles the workgroups per CU:
   // +8.5 % end to end, profiles/r01_ablation_probes.txt)
-  __shared__ __attribute__((aligned(16))) char lds[3 * PS];
+  constexpr int LDS_EPI = UPS == 1 ? conv_epilogue_vec_bytes(TM, TN) : 0;
+  __shared__ __attribute__((aligned(16))) char lds[3 * PS > LDS_EPI ? 3 * PS : LDS_EPI];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -205,6 +206,13 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
     __syncthreads();
   }
 
+  if constexpr (UPS == 1) {
+    if (p.vec4) {
+      conv_epilogue_vec<TM, TN>(p, acc, lds + wave * (LDS_EPI / 4), m_blk + wm * (BM / WM),
+                                n_blk + wn * (BN / WN), lane);
+      return;
+    }
+  }
   const int col_l = lane & 15, row_l = (lane >> 4) * 4;
   conv_epilogue<F32, TM, TN, UPS>(p, acc, m_blk + wm * (BM / WM) + row_l,
                                   n_blk + wn * (BN / WN) + col_l);
