@@ -238,3 +238,33 @@ def test_bf16x3_split_is_exact():
     assert not planes[..., 48:].any()
     back = join_bf16x3(planes, 48)
     assert np.array_equal(back, a)
+
+
+def test_f32x6_plan_packs_the_same_weights_as_planes(hrnet):
+    """The f32x6 plan stores every conv weight as [Cout, 3, Kp] bf16 planes whose sum is,
+    bit for bit, the float32 weight of the f32 plan (same ops, same offsets elsewhere)."""
+    from shapy_amd.utils.split import join_bf16x3
+    Pf = hrnet._build_plan(64, 64)
+    Px = hrnet._build_plan(64, 64, x6=True)
+    assert len(Pf.ops) == len(Px.ops)
+    blob_f = np.frombuffer(b''.join(Pf.wchunks), np.uint8)
+    blob_x = np.frombuffer(b''.join(Px.wchunks), np.uint8)
+    checked = 0
+    for of, ox in zip(Pf.ops, Px.ops):
+        for k in ('type', 'Cin', 'Cout', 'ksize', 'stride', 'Hi', 'Wi', 'relu', 'ups'):
+            assert of[k] == ox[k]
+        if of['type'] != 0 or checked >= 12:
+            continue
+        K = of['ksize'] ** 2 * of['Cin']
+        Kp = (K + 31) // 32 * 32
+        w = blob_f[of['wgt_off'] * 4:][:of['Cout'] * K * 4].view(np.float32).reshape(of['Cout'], K)
+        planes = blob_x[ox['wgt_off'] * 4:][:of['Cout'] * 3 * Kp * 2].view(np.uint16)
+        planes = planes.reshape(of['Cout'], 3, Kp)
+        assert np.array_equal(join_bf16x3(planes, K), w)
+        assert not planes[:, :, K:].any()
+        # the biases stay float32 in both plans
+        bf = blob_f[of['bias_off'] * 4:][:of['Cout'] * 4].view(np.float32)
+        bx = blob_x[ox['bias_off'] * 4:][:of['Cout'] * 4].view(np.float32)
+        assert np.array_equal(bf, bx)
+        checked += 1
+    assert checked == 12
