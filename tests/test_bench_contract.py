@@ -1,0 +1,36 @@
+"""The bench line committed under profiles/ carries every field of the driver's contract
+(bench.py docstring; roofline / cpu_baseline objects of the tier framing)."""
+import json
+import os.path as osp
+
+import pytest
+
+ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
+
+
+@pytest.mark.parametrize('name', ['r01_bench_f32.json', 'r01_bench_f32x6.json', 'r01_bench_bf16.json'])
+def test_committed_bench_line_has_the_contract_fields(name):
+    with open(osp.join(ROOT, 'profiles', name)) as f:
+        r = json.loads(f.read().strip().splitlines()[-1])
+    with open(osp.join(ROOT, 'BASELINE.json')) as f:
+        base = json.load(f)
+    assert r['metric'] == base['metric'].replace('\u00d7', 'x')
+    for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+              'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert k in r, k
+    assert r['unit'] == 'images/sec' and r['higher_is_better'] is True and r['scaling'] == 'weak'
+    assert r['vs_baseline'] is None and r['data'] == 'synthetic'       # BASELINE.md publishes nothing
+    assert 'workload' in r['config'] and 'model' not in r['config']
+    assert abs(r['value'] - r['config']['global_batch'] * 1e3 / r['ms_per_step']) < 1e-6 * r['value']
+    rf = r['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in rf, k
+    assert rf['bound'] in ('hbm', 'mfma') and rf['unit'] == 'TFLOP/s'
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    assert 0.0 < rf['frac'] < 1.0
+    if r['dtype'] == 'f32':
+        assert rf['peak'] == 157.3 and isinstance(rf['traffic'], float)
+        cb = r['cpu_baseline']
+        for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+            assert k in cb, k
+        assert cb['kind'] in ('reference', 'port') and cb['cores'] >= 1 and cb['value'] > 0
