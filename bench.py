@@ -34,6 +34,15 @@ F32_MFMA_PEAK_TFLOPS = 157.3                       # MI355X_MICROARCH.md, dense 
 BF16_MFMA_PEAK_TFLOPS = 2500.0                     # dense bf16 MFMA (not the 2:1-sparse figure)
 
 
+def baseline_metric():
+    """The metric string of BASELINE.json, verbatim."""
+    try:
+        with open(osp.join(ROOT, 'BASELINE.json')) as fh:
+            return json.load(fh)['metric']
+    except (OSError, KeyError, ValueError):
+        return 'images/sec whole-node (HRNet+SMPL-X fwd), 224\u00d7224 bs=64; betas L2 vs CPU'
+
+
 def conv_flop_per_image(net, size):
     plan = net.backbone._build_plan(size, size)      # f32 plan: algorithmic (unpadded) MACs
     macs = sum(o['Ho'] * o['Wo'] * o['Cout'] * o['Cin'] * o['ksize'] ** 2
@@ -188,7 +197,7 @@ def main():
     traffic = pmc_traffic(B, args.size) if args.dtype == 'f32' else None
     if rank == 0:
         res = {
-            'metric': 'images/sec whole-node (HRNet+SMPL-X fwd), 224x224 bs=64; betas L2 vs CPU',
+            'metric': baseline_metric(),
             'value': world * B * args.steps / dt,
             'unit': 'images/sec',
             'n_gpus': world,
