@@ -1,27 +1,37 @@
 """Headline benchmark: images/sec of the SHAPY hot path (HRNet-W48 + iterative regressor +
 SMPL-X + virtual measurements) on synthetic 224x224 crops, batch 64 per GPU, float32.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5          # BASELINE configs[1] (default)
+    python bench.py --gpus 8                                # spawns its own 8 RCCL ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --workload measurements --meshes 1000   # BASELINE configs[3]
+    python bench.py --workload smplx --batch 64             # SMPL-X layer alone (LBS evidence)
 
-One "step" = one full forward of the regressor on one batch that is already resident in HBM
-(BASELINE.json configs[1]: "HRNet-W48 + SMPL-X head, random-init weights, 224x224 bs=64 fp32
-on 1xMI355X"); with N > 1 every rank runs its own shard (weak scaling: 64 images per GPU) and
-the predicted betas are all-gathered with RCCL at the end of every step.
+One "step" of the default workload = one full forward of the regressor on one batch that is
+already resident in HBM (BASELINE.json configs[1]: "HRNet-W48 + SMPL-X head, random-init
+weights, 224x224 bs=64 fp32 on 1xMI355X"); with N > 1 every rank runs its own shard (weak
+scaling: 64 images per GPU) and the predicted betas are all-gathered with RCCL once per step on
+a side stream (joined when the next step issues its gather, shapy_amd/parallel.py).
 
 Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
-  roofline      the MFMA roofline of the dominant kernel family (conv_igemm_f32, 330 launches
-                per backbone forward): algorithmic conv FLOPs (2 x 18,466,524,160 MAC per image,
-                SURVEY.md 8d) / time of the backbone call, measured with HIP events on the
-                launch stream inside the timed loop; peak = 157.3 TFLOP/s (f32 MFMA, dense)
-  cpu_baseline  the CPU oracle (torch CPU restatement of the reference, "port") timed on this
+  roofline      the roofline of the dominant kernel family.  regressor: MFMA, algorithmic conv
+                FLOPs (2 x 18,466,524,160 MAC per image) / time of the backbone
+                call, measured with HIP events on the launch stream inside the timed loop, peak
+                157.3 TFLOP/s (f32 MFMA, dense).  measurements / smplx: HBM, algorithmic bytes
+                (376.6 KB per mesh; 65.4 MB constants + 254.4 KB per body) / time
+                of the launch group, peak 8 TB/s
+  parity        (regressor) error of the LAST timed batch against the CPU oracle, computed after
+                the timed region: the "betas L2 vs CPU" half of BASELINE.json's metric
+  cpu_baseline  the CPU oracle ("port": torch-CPU restatement of the reference) timed on this
                 host's cores on a bounded sample of the same workload
+  rccl_ranks / per_rank   (N > 1) number of RCCL ranks and each rank's own images/s
 """
 import argparse
 import json
 import os
 import os.path as osp
+import subprocess
 import sys
 import time
 
@@ -32,6 +42,10 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 CONV_FLOP_PER_IMAGE_224 = 2 * 18_466_524_160       # SURVEY.md 8(d), counted from the reference
 F32_MFMA_PEAK_TFLOPS = 157.3                       # MI355X_MICROARCH.md, dense f32 MFMA
 BF16_MFMA_PEAK_TFLOPS = 2500.0                     # dense bf16 MFMA (not the 2:1-sparse figure)
+HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md (6,290 GB/s achievable)
+MEASURE_BYTES_PER_MESH = 10475 * 12 + 20908 * 12   # v_shaped f32 + int32 faces = 376.6 KB (8d)
+SMPLX_CONST_BYTES = 65.4e6                         # posedirs + weights + J_regressor + ... (8d)
+SMPLX_BYTES_PER_BODY = 2 * 125_700 + 3_000         # vertices + v_shaped written, params read
 
 
 def baseline_metric():
@@ -40,7 +54,7 @@ def baseline_metric():
         with open(osp.join(ROOT, 'BASELINE.json')) as fh:
             return json.load(fh)['metric']
     except (OSError, KeyError, ValueError):
-        return 'images/sec whole-node (HRNet+SMPL-X fwd), 224\u00d7224 bs=64; betas L2 vs CPU'
+        return 'images/sec whole-node (HRNet+SMPL-X fwd), 224×224 bs=64; betas L2 vs CPU'
 
 
 def conv_flop_per_image(net, size):
@@ -50,69 +64,242 @@ def conv_flop_per_image(net, size):
     return 2 * macs
 
 
-def pmc_traffic(batch, size):
+def pmc_traffic(batch, size, dtype='f32'):
     """HBM bytes per backbone forward from the committed rocprofv3 --pmc passes
-    (profiles/*_pmc_hbm_traffic.json; FETCH_SIZE and WRITE_SIZE need separate passes and cannot
+    (profiles/*_pmc_hbm_traffic*.json; FETCH_SIZE and WRITE_SIZE need separate passes and cannot
     be collected from inside this process).  None when the workload differs."""
     import glob
-    for f in sorted(glob.glob(osp.join(ROOT, 'profiles', '*_pmc_hbm_traffic.json')), reverse=True):
+    for f in sorted(glob.glob(osp.join(ROOT, 'profiles', '*_pmc_hbm_traffic*.json')), reverse=True):
         with open(f) as fh:
             d = json.load(fh)
         h = d.get('hbm_bytes_per_backbone_forward', {})
-        if h.get('batch') == batch and h.get('size') == size:
+        if h.get('batch') == batch and h.get('size') == size and h.get('dtype', 'f32') == dtype:
             return {'bytes_as_reported': h['as_reported'], 'bytes_fetch_x2_corrected':
                     h['fetch_x2_corrected'], 'source': osp.relpath(f, ROOT)}
     return None
 
 
-def cpu_baseline(batch, size, budget_s=15.0):
-    """Times the CPU oracle (kind 'port') for about `budget_s` seconds of work."""
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as fh:
+            return next((ln.split(':', 1)[1].strip() for ln in fh if ln.startswith('model name')), '')
+    except OSError:
+        return ''
+
+
+def cpu_baseline_and_parity(x_np, out, size):
+    """CPU oracle on the LAST timed batch (rank 0, after the timed region): its wall time is the
+    all-cores CPU baseline at the headline batch size, its result is the parity reference.
+    A second, single-thread sample (the reference pins its pools to one thread, demo.py:432)
+    is timed on a few images."""
     import numpy as np
     import torch
     import __graft_entry__ as ge
-    from shapy_amd.utils import synthetic as syn
+    state = ge.oracle_state(0)
     cores = min(torch.get_num_threads(), 64)      # more threads only add scheduling noise here
     torch.set_num_threads(cores)
-    b = min(batch, 16)
-    x = syn.synthetic_images(b, size, 1)
-    state = ge.oracle_state(0)
-    ge.oracle_forward(x[:1], state=state)                    # untimed warm-up pass
-    n, t0 = 0, time.perf_counter()
-    while True:
-        ge.oracle_forward(x, state=state)
-        n += b
-        if time.perf_counter() - t0 > budget_s:
-            break
+    ge.oracle_forward(x_np[:1], state=state)                      # untimed warm-up pass
+    t0 = time.perf_counter()
+    ref = ge.oracle_forward(x_np, state=state)
     dt = time.perf_counter() - t0
-    cpu = ''
-    try:
-        with open('/proc/cpuinfo') as fh:
-            cpu = next((ln.split(':', 1)[1].strip() for ln in fh if ln.startswith('model name')), '')
-    except OSError:
-        pass
-    return {'value': n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port', 'cpu_model': cpu,
-            'host_logical_cpus': os.cpu_count(),
-            'sample': f'{n} images ({size}x{size}, batches of {b}) through the CPU oracle '
-                      f'(torch-CPU HRNet + numpy SMPL-X + C intersection + scipy hull) in {dt:.1f} s'}
+    n = x_np.shape[0]
+    torch.set_num_threads(1)
+    n1 = min(n, 3)
+    ge.oracle_forward(x_np[:1], state=state)
+    t0 = time.perf_counter()
+    ge.oracle_forward(x_np[:n1], state=state)
+    dt1 = time.perf_counter() - t0
+    torch.set_num_threads(cores)
+    base = {'value': n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'cpu_model': cpu_model(), 'host_logical_cpus': os.cpu_count(),
+            'sample': f'{n} images ({size}x{size}, one batch of {n}) through the CPU oracle '
+                      f'(torch-CPU HRNet + numpy SMPL-X + C intersection + scipy hull) in {dt:.1f} s',
+            'single_thread': {'value': n1 / dt1, 'unit': 'images/sec', 'cores': 1,
+                              'sample': f'{n1} images (one batch) in {dt1:.1f} s with '
+                                        'torch.set_num_threads(1) (the reference pins its pools to '
+                                        '1 thread, demo.py:432)'}}
+    st, rs = out['stage_02'], ref['stages'][-1]
+    betas = st['betas'].float().cpu().numpy()
+    db = betas - rs['betas']
+    dv = st['vertices'].float().cpu().numpy() - rs['vertices']
+    par = {'n_images': int(n), 'reference': 'CPU oracle (float32, same seeded weights and images)',
+           'betas_l2': float(np.sqrt((db * db).sum(axis=1)).mean()),
+           'betas_l2_max': float(np.sqrt((db * db).sum(axis=1)).max()),
+           'betas_maxabs': float(np.abs(db).max()),
+           'vertices_maxabs': float(np.abs(dv).max()),
+           'features_maxabs': float(np.abs(out['features'].float().cpu().numpy() -
+                                           ref['features']).max()),
+           'tolerance': 1e-4}
+    if 'measurements' in out and 'measurements' in ref:
+        par['measurements_maxabs'] = {
+            k: float(np.abs(out['measurements'][k].float().cpu().numpy() - ref['measurements'][k]).max())
+            for k in ('mass', 'height', 'chest', 'waist', 'hips')}
+    return base, par
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='images per GPU')
-    ap.add_argument('--size', type=int, default=224)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--single-stream', action='store_true')
-    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
-                    help='replay the backbone as one hipGraph (auto: batches <= 8)')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'f32x6', 'bf16'],
-                    help='f32 = BASELINE configs[1] (headline) on the f32 matrix-core path; '
-                         'f32x6 = same float32 tensors, products from the exact 3-way bf16 split '
-                         '(6 bf16 MFMAs per product); bf16 = configs[2] storage type')
-    args = ap.parse_args()
+def self_spawn(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through
+    torch.distributed.run, the launch convention of regressor/evaluate.py:68-79 (env://)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), osp.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', SHAPY_BENCH_SPAWNED='1')
+    return subprocess.call(cmd, env=env)
 
+
+def hip_events(n):
+    import torch
+    return ([torch.cuda.Event(enable_timing=True) for _ in range(n)],
+            [torch.cuda.Event(enable_timing=True) for _ in range(n)])
+
+
+def config4_meshes(n, seed=0):
+    """v = s * sum_i w_i v_i, w ~ Dirichlet(1,1,1,1), s ~ U(0.9, 1.1)
+    over the 4 real v_shaped meshes; mesh 0 is the shipped sample itself."""
+    import numpy as np
+    from shapy_amd.utils import synthetic as syn
+    faces, meshes = syn.load_topology()
+    r = syn.rng_for(seed, 'config4')
+    w = r.dirichlet(np.ones(4), size=n).astype(np.float32)
+    s = r.uniform(0.9, 1.1, size=n).astype(np.float32)
+    w[0] = [1, 0, 0, 0]
+    s[0] = 1
+    v = (np.einsum('nk,kvc->nvc', w, meshes) * s[:, None, None]).astype(np.float32)
+    return faces, v
+
+
+# ------------------------------------------------------------------------------------------
+def run_measurements(args, rank, world):
+    """BASELINE configs[3]: virtual measurements of `--meshes` SMPL-X meshes (per GPU)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from shapy_amd.measurements import BodyMeasurements
+    data = osp.join(ROOT, 'shapy_amd', 'data')
+    bm = BodyMeasurements({'meas_definition_path': f'{data}/measurement_defitions.yaml',
+                           'meas_vertices_path': f'{data}/smplx_measurements.yaml',
+                           'max_collisions': 256}).cuda()
+    faces_np, v_np = config4_meshes(args.meshes, seed=rank)
+    v = torch.from_numpy(v_np).cuda()
+    f = torch.from_numpy(faces_np).cuda()
+    for _ in range(args.warmup):
+        out = bm.forward_vertices(v, f)
+    ev0, ev1 = hip_events(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record()
+        out = bm.forward_vertices(v, f)
+        ev1[i].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    nbytes = MEASURE_BYTES_PER_MESH * args.meshes
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    if rank != 0:
+        return None
+    res = {
+        'metric': 'meshes/sec, virtual measurements (mass, height, chest, waist, hips) of SMPL-X '
+                  'meshes; values vs CPU oracle',
+        'value': world * args.meshes * args.steps / dt, 'unit': 'meshes/sec', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': f'virtual measurements of {args.meshes} SMPL-X meshes per GPU '
+                               '(BASELINE configs[3]: convex mixtures of the 4 shipped v_shaped '
+                               'meshes, 10,475 vertices / 20,908 faces each), max_collisions 256',
+                   'meshes_per_gpu': args.meshes, 'parallelism': f'dp{world}'},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'frac_of_achievable_6290': achieved / 6290.0,
+                     'kernel': 'measure_scan_lds_kernel + measure_hull_wave_kernel (one launch '
+                               'group = both kernels; the time is the whole group)',
+                     'bytes_per_launch_group': nbytes, 'ms_per_launch_group': ms},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        import __graft_entry__ as ge
+        from oracle import measure as om
+        lm = ge.oracle_state(0)['lm']
+        n = min(args.meshes, 40)
+        om.body_measurements(v_np[:1][:, faces_np], lm)
+        t0 = time.perf_counter()
+        ref = om.body_measurements(v_np[:n][:, faces_np], lm)
+        dtc = time.perf_counter() - t0
+        got = out[:n].cpu().numpy()
+        res['cpu_baseline'] = {
+            'value': n / dtc, 'unit': 'meshes/sec', 'cores': 1, 'kind': 'port',
+            'cpu_model': cpu_model(),
+            'sample': f'{n} meshes through the CPU oracle (C brute-force intersection + scipy '
+                      f'ConvexHull, 1 thread) in {dtc:.1f} s'}
+        res['parity'] = {'n_meshes': n, 'reference': 'CPU oracle', 'maxabs': {
+            k: float(np.abs(got[:, i] - ref[k]).max())
+            for i, k in enumerate(('mass', 'height', 'chest', 'waist', 'hips'))}}
+    return res
+
+
+def run_smplx(args, rank, world):
+    """The SMPL-X layer alone (BASELINE configs[0] shape at --batch bodies): blend shapes,
+    joint regression, pose chain, skinning, landmarks.  HBM roofline per SURVEY.md 8(d)."""
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+    from shapy_amd.models.common.pose_utils import ContinuousRotReprDecoder
+    net, _ = ge.make_network()
+    B = args.batch
+    g = torch.Generator().manual_seed(0)
+    betas = torch.randn(B, 10, generator=g).cuda()
+    expr = (0.5 * torch.randn(B, 10, generator=g)).cuda()
+    p6 = torch.tensor([1., 0, 0, 1, 0, 0]).repeat(B, 22) + 0.3 * torch.randn(B, 132, generator=g)
+    rot = ContinuousRotReprDecoder(22).cuda()(p6.cuda())
+
+    def step():
+        with torch.no_grad():
+            return net.model(global_rot=rot[:, :1], body_pose=rot[:, 1:], betas=betas,
+                             expression=expr, get_skin=True, return_shaped=True)
+    for _ in range(args.warmup):
+        step()
+    ev0, ev1 = hip_events(args.steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record()
+        out = step()
+        ev1[i].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    nbytes = SMPLX_CONST_BYTES + SMPLX_BYTES_PER_BODY * B
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return {
+        'metric': 'bodies/sec, SMPL-X forward (betas/pose -> 10,475 vertices + 123 joints)',
+        'value': B * args.steps / dt, 'unit': 'bodies/sec', 'n_gpus': 1, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'SMPL-X layer forward, batch {B} (BASELINE configs[0] shape), '
+                               'synthetic model buffers', 'batch': B},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'kernel': 'SMPL-X launch group (blend-shape GEMMs, pose chain, skinning, '
+                               'landmarks); the time is the whole group incl. host gaps',
+                     'bytes_per_launch_group': nbytes, 'ms_per_launch_group': ms,
+                     'floor_us_at_6290': nbytes / 6290e9 * 1e6},
+    }
+
+
+def run_regressor(args, rank, world, local_rank):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -120,42 +307,29 @@ def main():
     from shapy_amd.utils import synthetic as syn
     from shapy_amd import parallel
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks '
-                         f'(WORLD_SIZE={world})')
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', init_method='env://')
-    if rank == 0 and not osp.exists(osp.join(ROOT, 'shapy_amd', 'csrc', 'libshapy_hip.so')):
-        from shapy_amd import build as hip_build      # fresh checkout: the library is git-ignored
-        hip_build.build()
-    if world > 1:
-        dist.barrier()
-
     net, _ = ge.make_network(model_folder=f'/tmp/shapy_synth_models_r{local_rank}' if world > 1
                              else '/tmp/shapy_synth_models')
     net.backbone.multi_stream = not args.single_stream
     net.backbone.compute_dtype = args.dtype
     net.backbone.use_graph = {'auto': 'auto', 'on': True, 'off': False}[args.graph]
+    if args.algo:
+        net.backbone.conv_algo = args.algo
     B = args.batch
     # distinct synthetic images per rank (global batch = world * B), resident in HBM
-    x = torch.from_numpy(syn.synthetic_images(B, args.size, 100 + rank)).cuda()
+    x_np = syn.synthetic_images(B, args.size, 100 + rank)
+    x = torch.from_numpy(x_np).cuda()
     gatherer = parallel.BetasGatherer(world)
 
     def step():
         with torch.no_grad():
             out = net(x, None)
-            betas = gatherer(out['stage_02']['betas'])
+            betas = gatherer(out['stage_02']['betas'])     # joined at the next call / wait()
         return out, betas
 
     for _ in range(args.warmup):
         step()
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    gatherer.wait()
+    ev0, ev1 = hip_events(args.steps)
     # events around the backbone call are recorded on the launch stream by a forward hook pair
     idx = {'i': 0}
     h0 = net.backbone.register_forward_pre_hook(lambda m, a: ev0[idx['i']].record())
@@ -169,17 +343,26 @@ def main():
     for i in range(args.steps):
         idx['i'] = i
         out, betas = step()
+    gatherer.wait()
     torch.cuda.synchronize()
+    own_dt = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     h0.remove(); h1.remove()
+    per_rank = None
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        own = torch.tensor([B * args.steps / own_dt], dtype=torch.float64, device='cuda')
+        allr = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(allr, own)
+        per_rank = [float(t.item()) for t in allr]
     assert betas.shape == (world * B, 10)
+    if world > 1:      # the gathered tensor really holds every rank's betas: own shard in place
+        assert torch.equal(betas[rank * B:(rank + 1) * B], out['stage_02']['betas'])
 
     backbone_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     flop_img = conv_flop_per_image(net, args.size)
@@ -192,48 +375,118 @@ def main():
               'bf16': 'conv_igemm_kernel<BF16> (v_mfma_f32_16x16x32_bf16)',
               'f32x6': 'conv_x6_kernel (6 x v_mfma_f32_16x16x32_bf16 per f32 product; peak = '
                        'dense bf16 peak / 6)'}[args.dtype]
+    algo = getattr(net.backbone, 'conv_algo', 'direct')
+    if args.dtype == 'f32' and algo != 'direct':
+        kernel += f' + conv_wino_kernel (Winograd F(2x2,3x3) for the 3x3 stride-1 layers, ' \
+                  f'algo={algo}; achieved counts the ALGORITHMIC direct-conv FLOPs)'
     # HBM bytes per launch group (one backbone forward) from the committed PMC passes, gfx950
-    # FETCH x2 correction applied; measured on the f32 build
-    traffic = pmc_traffic(B, args.size) if args.dtype == 'f32' else None
+    # FETCH x2 correction applied
+    traffic = pmc_traffic(B, args.size, args.dtype)
+    if rank != 0:
+        return None
+    res = {
+        'metric': baseline_metric(),
+        'value': world * B * args.steps / dt,
+        'unit': 'images/sec',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': args.dtype,
+        'data': 'synthetic',
+        'config': {'workload': f'HRNet-W48 + iterative regressor + SMPL-X + virtual '
+                               f'measurements, random-init weights, {args.size}x{args.size}, '
+                               f'bs={B} per GPU, ' + {
+                                   'f32': 'fp32 (BASELINE configs[1])',
+                                   'f32x6': 'fp32 tensors, bf16x6 split products '
+                                            '(BASELINE configs[1])',
+                                   'bf16': 'bf16 storage / f32 accumulate (BASELINE '
+                                           'configs[2] precision)'}[args.dtype],
+                   'global_batch': world * B, 'parallelism': f'dp{world}',
+                   'multi_stream': not args.single_stream, 'conv_algo': algo,
+                   'hip_graph': bool(net.backbone.use_graph is True or
+                                     (net.backbone.use_graph == 'auto' and
+                                      B <= net.backbone.graph_max_batch))},
+        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak,
+                     'unit': 'TFLOP/s', 'frac': achieved / peak,
+                     'traffic': traffic['bytes_fetch_x2_corrected'] if traffic else None,
+                     'traffic_detail': traffic,
+                     'peak_sustained_measured': {'f32': 141.0, 'bf16': 1410.0,
+                                                 'f32x6': 1410.0 / 6.0}[args.dtype],
+                     'kernel': kernel + ', 330 launches per backbone forward',
+                     'flop_per_launch_group': flop_img * B,
+                     'ms_per_launch_group': backbone_ms},
+    }
+    if world > 1:
+        res['rccl_ranks'] = world
+        res['per_rank'] = {'images_per_sec': per_rank,
+                           'allgather': {'issued': gatherer.issued,
+                                         'joined_by_next_step': gatherer.deferred_waits}}
+    if not args.no_cpu_baseline:                     # rank 0 only; oracle outside the timed region
+        base, par = cpu_baseline_and_parity(x_np, out, args.size)
+        res['parity'] = par
+        if world == 1:
+            res['cpu_baseline'] = base
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='regressor', choices=['regressor', 'measurements', 'smplx'],
+                    help='regressor = BASELINE configs[1] (headline); measurements = configs[3]; '
+                         'smplx = the SMPL-X layer alone (configs[0] shape)')
+    ap.add_argument('--batch', type=int, default=64, help='images (bodies) per GPU')
+    ap.add_argument('--meshes', type=int, default=1000, help='meshes per GPU (measurements)')
+    ap.add_argument('--size', type=int, default=224)
+    ap.add_argument('--no-cpu-baseline', action='store_true',
+                    help='skip the CPU oracle (cpu_baseline and parity fields)')
+    ap.add_argument('--single-stream', action='store_true')
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
+                    help='replay the backbone as one hipGraph (auto: batches <= 8)')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f32x6', 'bf16'],
+                    help='f32 = BASELINE configs[1] (headline) on the f32 matrix-core path; '
+                         'f32x6 = same float32 tensors, products from the exact 3-way bf16 split '
+                         '(6 bf16 MFMAs per product); bf16 = configs[2] storage type')
+    ap.add_argument('--algo', default=None, choices=['direct', 'auto', 'winograd'],
+                    help='f32 conv algorithm override (default: the backbone\'s own default)')
+    args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_spawn(args.gpus))
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with '
+                         f'--nproc-per-node {args.gpus} (or without a launcher: bench.py spawns '
+                         'its own ranks)')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', init_method='env://')
+    if rank == 0 and not osp.exists(osp.join(ROOT, 'shapy_amd', 'csrc', 'libshapy_hip.so')):
+        from shapy_amd import build as hip_build      # fresh checkout: the library is git-ignored
+        hip_build.build()
+    if world > 1:
+        dist.barrier()
+
+    if args.workload == 'measurements':
+        res = run_measurements(args, rank, world)
+    elif args.workload == 'smplx':
+        res = run_smplx(args, rank, world)
+    else:
+        res = run_regressor(args, rank, world, local_rank)
     if rank == 0:
-        res = {
-            'metric': baseline_metric(),
-            'value': world * B * args.steps / dt,
-            'unit': 'images/sec',
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': args.dtype,
-            'data': 'synthetic',
-            'config': {'workload': f'HRNet-W48 + iterative regressor + SMPL-X + virtual '
-                                   f'measurements, random-init weights, {args.size}x{args.size}, '
-                                   f'bs={B} per GPU, ' + {
-                                       'f32': 'fp32 (BASELINE configs[1])',
-                                       'f32x6': 'fp32 tensors, bf16x6 split products '
-                                                '(BASELINE configs[1])',
-                                       'bf16': 'bf16 storage / f32 accumulate (BASELINE '
-                                               'configs[2] precision)'}[args.dtype],
-                       'global_batch': world * B, 'parallelism': f'dp{world}',
-                       'multi_stream': not args.single_stream,
-                       'hip_graph': bool(net.backbone.use_graph is True or
-                                         (net.backbone.use_graph == 'auto' and
-                                          B <= net.backbone.graph_max_batch))},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak,
-                         'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': traffic['bytes_fetch_x2_corrected'] if traffic else None,
-                         'traffic_detail': traffic,
-                         'peak_sustained_measured': {'f32': 141.0, 'bf16': 1410.0,
-                                                     'f32x6': 1410.0 / 6.0}[args.dtype],
-                         'kernel': kernel + ', 330 launches per backbone forward',
-                         'flop_per_launch_group': flop_img * B,
-                         'ms_per_launch_group': backbone_ms},
-        }
-        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
-            res['cpu_baseline'] = cpu_baseline(B, args.size)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -99,6 +99,8 @@ def main(exp_cfg, demo_output_folder='demo_output', focal_length=5000, sensor_wi
         start = time.perf_counter()
         out = model(body_imgs, targets)
         torch.cuda.synchronize()
+        if getattr(model, 'compute_measurements', False):
+            model.body_measurements.check_overflow()
         total_time += time.perf_counter() - start
         cnt += 1
 

@@ -44,6 +44,7 @@ def main(demo_input_folder, demo_output_folder, meas_definition_path, meas_verti
         betas = torch.from_numpy(np.asarray(betas, np.float32)).to(device).reshape(1, -1)
         v_shaped = smpl.forward_shape(betas)['v_shaped']
         vals = bm.forward_vertices(v_shaped, faces)[0].cpu().numpy()
+        bm.check_overflow()
         meas = dict(zip(bm.NAMES, [float(v) for v in vals]))
         print('    Virtual measurements: ' + ''.join(
             f'    {k}: {v:.2f} {"kg" if k == "mass" else "m"}' for k, v in meas.items()))

@@ -10,11 +10,12 @@
 //    (HBM/L2-bound, coalesced) and compacts hits with wave ballots.  Larger query meshes go
 //    through the LBVH in bvh.hip.
 //  * shapy_body_measure_f32: BodyMeasurements.forward (body_measurements.py:99-246) fused:
-//    one scan over the faces of v_shaped computes the signed-volume partial sums and the
-//    plane/triangle hits of all three planes (no [B,F,3,3] triangle tensor is materialised),
-//    then one workgroup per (mesh, plane) sorts the <= 2*max_coll points in LDS and walks the
-//    2-D convex hull (monotone chain with exact float64 orientation tests) -- replacing the
-//    per-mesh scipy/Qhull call and the D2H copy in front of it.
+//    one workgroup per mesh stages v_shaped in LDS, scans the face table once (signed-volume
+//    sum + y-range candidates of all three planes; no [B,F,3,3] triangle tensor is
+//    materialised) and runs the SAT / intersection-point code on the dense candidate queue;
+//    then one wave per (mesh, plane) sorts the <= 2*max_coll points in LDS and walks the 2-D
+//    convex hull (monotone chain, float64 orientation tests) -- replacing the per-mesh
+//    scipy/Qhull call and the D2H copy in front of it.
 //
 // This translation unit is compiled with -ffp-contract=off so that every float32 decision
 // (SAT tolerance tests, barycentric range tests) is bit-identical with the CPU oracle.
@@ -96,113 +97,194 @@ struct Landmarks {
   float bc[5][3];
 };
 
-__device__ __forceinline__ float lm_coord(const float *vb, const int32_t *faces, const Landmarks &lm,
+// (tri * bc.reshape(1,3,1)).sum(dim=1)   (body_measurements.py:130-131,185-195)
+template <typename VF>
+__device__ __forceinline__ float lm_coord(VF vtx, const int32_t *faces, const Landmarks &lm,
                                           int which, int axis) {
   const int f = lm.face[which];
-  const float a = vb[(long)faces[f * 3 + 0] * 3 + axis];
-  const float b = vb[(long)faces[f * 3 + 1] * 3 + axis];
-  const float c = vb[(long)faces[f * 3 + 2] * 3 + axis];
-  // (tri * bc.reshape(1,3,1)).sum(dim=1)   (body_measurements.py:130-131,185-195)
+  const float a = vtx(faces[f * 3 + 0], axis), b = vtx(faces[f * 3 + 1], axis),
+              c = vtx(faces[f * 3 + 2], axis);
   return (a * lm.bc[which][0] + b * lm.bc[which][1]) + c * lm.bc[which][2];
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void measure_scan_kernel(
-    const float *__restrict__ v_shaped, const int32_t *__restrict__ faces, int V, int F, int MC,
-    Landmarks lm, int *__restrict__ counters, float *__restrict__ vol_partial,
+constexpr int M2_THREADS = 1024;            // 16 waves: one workgroup owns a CU's LDS
+constexpr int M2_QCAP = 4096;               // candidate queue entries (face * 4 + plane)
+constexpr int M2_MAX_SLICES = 16;
+constexpr int M2_STATIC_LDS = M2_QCAP * 4 + 512;
+constexpr int M2_LDS_TOTAL = 160 * 1024;
+
+// One workgroup per (mesh slice, mesh).  STAGED: the mesh's v_shaped (V * 12 bytes; 125.7 KB for
+// SMPL-X) is copied ONCE, coalesced, into LDS and the 9 coordinate gathers per face are LDS
+// reads; the int32 face table streams through in index order (12 contiguous bytes per lane).
+// The scan itself only evaluates the signed-volume term and the y-range test against the three
+// plane heights; faces that pass (~0.7 % per plane) are queued in LDS and the expensive part
+// -- AABB + 11-axis SAT + first-hit point for both plane triangles -- runs afterwards on the
+// dense queue (in the scan it would run with 1-2 active lanes in 3 of 4 wave iterations).
+// Hit slots come from one global atomic per hit (~300 per mesh); the hull kernel sorts, so the
+// order does not matter.  !STAGED (triangle soups of the reference signature, V = 3 F): same
+// code, coordinates gathered from global memory, the faces of a mesh split over several slices.
+template <bool STAGED>
+__global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
+    const float *__restrict__ v_shaped, const int32_t *__restrict__ faces, int V, int F, int Fs,
+    int CAP, Landmarks lm, int *__restrict__ counters, float *__restrict__ vol_partial,
     float4 *__restrict__ points) {
+  extern __shared__ __attribute__((aligned(16))) float sv[];
+  __shared__ int queue[M2_QCAP];
+  __shared__ int qn;
   __shared__ float hs[3];
-  __shared__ double red[SCAN_THREADS / 64];
-  const int b = blockIdx.y;
+  __shared__ double red[M2_THREADS / 64];
+  const int b = blockIdx.y, tid = threadIdx.x;
   const float *vb = v_shaped + (long)b * V * 3;
-  if (threadIdx.x < 3) hs[threadIdx.x] = lm_coord(vb, faces, lm, 2 + threadIdx.x, 1);
+  int shift = 0;
+  if constexpr (STAGED) {
+    // 16-byte copies: mesh b starts at byte b * V * 12, which is only 4-byte aligned; the LDS
+    // image is shifted by the same phase so that both sides of the vector copy are aligned
+    const int N = V * 3;
+    int head = (int)(((16 - ((uintptr_t)vb & 15)) & 15) >> 2);
+    if (head > N) head = N;
+    shift = (4 - head) & 3;
+    if (tid < head) sv[shift + tid] = vb[tid];
+    const int n4 = (N - head) >> 2;
+    const float4 *g4 = reinterpret_cast<const float4 *>(vb + head);
+    float4 *s4 = reinterpret_cast<float4 *>(sv + shift + head);
+    for (int i = tid; i < n4; i += M2_THREADS) s4[i] = g4[i];
+    for (int i = head + n4 * 4 + tid; i < N; i += M2_THREADS) sv[shift + i] = vb[i];
+  }
+  if (tid == 0) qn = 0;
   __syncthreads();
-  const int f = blockIdx.x * SCAN_THREADS + threadIdx.x;
-  double vol = 0.0;
-  if (f < F) {
+  auto vtx = [&](int idx, int c) -> float {
+    if constexpr (STAGED) return sv[shift + idx * 3 + c];
+    else return vb[(long)idx * 3 + c];
+  };
+  if (tid < 3) hs[tid] = lm_coord(vtx, faces, lm, 2 + tid, 1);
+  __syncthreads();
+  auto load_face = [&](int f) -> Tri {
     const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
     Tri t;
-    t.v0 = v3(vb[(long)i0 * 3], vb[(long)i0 * 3 + 1], vb[(long)i0 * 3 + 2]);
-    t.v1 = v3(vb[(long)i1 * 3], vb[(long)i1 * 3 + 1], vb[(long)i1 * 3 + 2]);
-    t.v2 = v3(vb[(long)i2 * 3], vb[(long)i2 * 3 + 1], vb[(long)i2 * 3 + 2]);
-    // compute_mass (body_measurements.py:201-215), term order as written there
-    const float x0 = t.v0.x, y0 = t.v0.y, z0 = t.v0.z, x1 = t.v1.x, y1 = t.v1.y, z1 = t.v1.z,
-                x2 = t.v2.x, y2 = t.v2.y, z2 = t.v2.z;
-    const float vv = -x2 * y1 * z0 + x1 * y2 * z0 + x2 * y0 * z1 - x0 * y2 * z1 - x1 * y0 * z2 +
-                     x0 * y1 * z2;
-    vol = (double)vv;
-    const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    t.v0 = v3(vtx(i0, 0), vtx(i0, 1), vtx(i0, 2));
+    t.v1 = v3(vtx(i1, 0), vtx(i1, 1), vtx(i1, 2));
+    t.v2 = v3(vtx(i2, 0), vtx(i2, 1), vtx(i2, 2));
+    return t;
+  };
+  auto drain = [&]() {
+    const int n = qn < M2_QCAP ? qn : M2_QCAP;
+    for (int p = tid; p < 2 * n; p += M2_THREADS) {
+      const int c = queue[p >> 1], qi = p & 1, f = c >> 2, pl = c & 3;
+      const Tri t = load_face(f);
       const float h = hs[pl];
-      if (!(ymin <= h && ymax >= h)) continue;
-      // _get_plane_at_heights (body_measurements.py:86-97)
-      const V3 c0 = v3(-1.f, h, -1.f), c1 = v3(1.f, h, -1.f), c2 = v3(1.f, h, 1.f),
-               c3 = v3(-1.f, h, 1.f);
+      // _get_plane_at_heights (body_measurements.py:86-97): quad (c0,c1,c2,c3) as 2 triangles
+      Tri q;
+      q.v0 = v3(-1.f, h, -1.f);
+      q.v1 = qi == 0 ? v3(1.f, h, -1.f) : v3(1.f, h, 1.f);
+      q.v2 = qi == 0 ? v3(1.f, h, 1.f) : v3(-1.f, h, 1.f);
+      if (!(aabb_overlap(q, t) && tri_tri_sat(q, t))) continue;
+      const long list = ((long)b * 3 + pl) * 2 + qi;
+      const int slot = atomicAdd(counters + list, 1);
+      if (slot >= CAP) continue;
+      V3 bc = v3(0.f, 0.f, 0.f);
+      tri_tri_point(q, t, bc);
+      // points = sum_k bc_k * tri_k (body_measurements.py:144-147)
+      float4 pt;
+      pt.x = (t.v0.x * bc.x + t.v1.x * bc.y) + t.v2.x * bc.z;
+      pt.y = (t.v0.y * bc.x + t.v1.y * bc.y) + t.v2.y * bc.z;
+      pt.z = (t.v0.z * bc.x + t.v1.z * bc.y) + t.v2.z * bc.z;
+      pt.w = __int_as_float(f);
+      points[list * CAP + slot] = pt;
+    }
+  };
+
+  const int f_lo = blockIdx.x * Fs, f_hi = min(F, f_lo + Fs);
+  double vol = 0.0;
+  for (int f0 = f_lo; f0 < f_hi; f0 += M2_THREADS) {
+    const int f = f0 + tid;
+    if (f < f_hi) {
+      const Tri t = load_face(f);
+      // compute_mass (body_measurements.py:201-215), term order as written there
+      const float x0 = t.v0.x, y0 = t.v0.y, z0 = t.v0.z, x1 = t.v1.x, y1 = t.v1.y, z1 = t.v1.z,
+                  x2 = t.v2.x, y2 = t.v2.y, z2 = t.v2.z;
+      const float vv = -x2 * y1 * z0 + x1 * y2 * z0 + x2 * y0 * z1 - x0 * y2 * z1 - x1 * y0 * z2 +
+                       x0 * y1 * z2;
+      vol += (double)vv;
+      const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
 #pragma unroll
-      for (int qi = 0; qi < 2; ++qi) {
-        Tri q;
-        q.v0 = c0;
-        q.v1 = qi == 0 ? c1 : c2;
-        q.v2 = qi == 0 ? c2 : c3;
-        if (!(aabb_overlap(q, t) && tri_tri_sat(q, t))) continue;
-        int *cnt = counters + ((long)b * 3 + pl) * 2 + qi;
-        const int slot = atomicAdd(cnt, 1);
-        if (slot >= MC) continue;
-        V3 bc = v3(0.f, 0.f, 0.f);
-        tri_tri_point(q, t, bc);
-        // points = sum_k bc_k * tri_k (body_measurements.py:144-147)
-        float4 pt;
-        pt.x = (t.v0.x * bc.x + t.v1.x * bc.y) + t.v2.x * bc.z;
-        pt.y = (t.v0.y * bc.x + t.v1.y * bc.y) + t.v2.y * bc.z;
-        pt.z = (t.v0.z * bc.x + t.v1.z * bc.y) + t.v2.z * bc.z;
-        pt.w = __int_as_float(f);
-        points[(((long)b * 3 + pl) * 2 + qi) * MC + slot] = pt;
-      }
+      for (int pl = 0; pl < 3; ++pl)
+        if (ymin <= hs[pl] && ymax >= hs[pl]) {      // the y part of the AABB test
+          const int slot = atomicAdd(&qn, 1);
+          if (slot < M2_QCAP) queue[slot] = f * 4 + pl;
+        }
+    }
+    __syncthreads();
+    // a chunk adds at most 3 entries per thread: drain before the queue could overflow
+    if (qn > M2_QCAP - 3 * M2_THREADS) {
+      drain();
+      __syncthreads();
+      if (tid == 0) qn = 0;
+      __syncthreads();
     }
   }
-  // deterministic block reduction of the signed volume
+  drain();
+  // deterministic reduction of the signed volume (fixed lane / wave order)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) vol += __shfl_xor(vol, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vol;
+  if ((tid & 63) == 0) red[tid >> 6] = vol;
   __syncthreads();
-  if (threadIdx.x == 0)
-    vol_partial[(long)b * gridDim.x + blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+  if (tid == 0) {
+    double sum = 0.0;
+    for (int w = 0; w < M2_THREADS / 64; ++w) sum += red[w];
+    vol_partial[(long)b * gridDim.x + blockIdx.x] = (float)sum;
+  }
 }
 
-constexpr int HULL_MAX = 1024;
-
-__global__ __launch_bounds__(256) void measure_hull_kernel(
-    const float *__restrict__ v_shaped, const int32_t *__restrict__ faces, int V, int MC,
-    int n_vol_blocks, Landmarks lm, const int *__restrict__ counters,
+// One wave per (mesh, plane): gather the <= 2 * MC points of the two plane triangles, bitonic
+// sort by (x, z, y) in LDS (the result is a pure function of the point SET: the atomic order of
+// the scan does not matter), Andrew's monotone chain in the (x, z) plane with float64
+// orientation tests, perimeter in 3-D (body_measurements.py:160-179).  One wave instead of one
+// workgroup per hull: the chain is serial either way, and 3,000 waves of 1,000 meshes are all
+// resident at once (<= 10 KB of LDS each).
+// Overflow (more than MC hits of one plane triangle): the MC LOWEST face indices are kept, the
+// rule of the ascending-order CPU oracle -- deterministic as long as the scan could store all
+// hits (CAP = 2 MC slots per list); the excess is counted in *overflow either way.
+__global__ __launch_bounds__(64) void measure_hull2_kernel(
+    const float *__restrict__ v_shaped, const int32_t *__restrict__ faces, int V, int MC, int CAP,
+    int NP, int n_slices, Landmarks lm, const int *__restrict__ counters,
     const float *__restrict__ vol_partial, const float4 *__restrict__ points,
     float *__restrict__ out, int *__restrict__ overflow) {
-  __shared__ float px[HULL_MAX], py[HULL_MAX], pz[HULL_MAX];
-  __shared__ int stack[HULL_MAX + 1];
-  const int pl = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const int *cnt = counters + ((long)b * 3 + pl) * 2;
-  const int c0 = cnt[0], c1 = cnt[1];
-  const int n0 = min(c0, MC), n1 = min(c1, MC);
-  if (tid == 0 && overflow && (c0 > MC || c1 > MC)) atomicAdd(overflow, (c0 - n0) + (c1 - n1));
-  // gather valid points: the reference keeps slots with collision_faces > 0 (:161), i.e. it
-  // drops face 0 as well as the empty (-1) slots
-  int npow = 1;
+  extern __shared__ __attribute__((aligned(16))) float hl[];
+  float *px = hl, *py = hl + NP, *pz = hl + 2 * NP;
+  int *stack = reinterpret_cast<int *>(hl + 3 * NP);           // NP + 1 entries
+  const int pl = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const long list0 = ((long)b * 3 + pl) * 2;
+  const int c0 = counters[list0], c1 = counters[list0 + 1];
+  const int m0 = min(c0, CAP), m1 = min(c1, CAP);              // stored
+  const int n0 = min(c0, MC), n1 = min(c1, MC);                // kept
+  if (lane == 0 && overflow && (c0 > MC || c1 > MC)) atomicAdd(overflow, (c0 - n0) + (c1 - n1));
+  int npow = 2;
   while (npow < n0 + n1) npow <<= 1;
-  if (npow < 2) npow = 2;
-  for (int i = tid; i < npow; i += 256) {
-    float x = INFINITY, y = 0.f, z = INFINITY;
-    if (i < n0 + n1) {
-      const int qi = i < n0 ? 0 : 1;
-      const float4 p = points[(((long)b * 3 + pl) * 2 + qi) * MC + (i < n0 ? i : i - n0)];
-      if (__float_as_int(p.w) > 0) { x = p.x; y = p.y; z = p.z; }
+  for (int i = lane; i < npow; i += 64) { px[i] = INFINITY; py[i] = 0.f; pz[i] = INFINITY; }
+  __syncthreads();
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    const int m = qi ? m1 : m0, n = qi ? n1 : n0, base = qi ? n0 : 0;
+    const float4 *pp = points + (list0 + qi) * CAP;
+    for (int i = lane; i < m; i += 64) {
+      const float4 p = pp[i];
+      const int face = __float_as_int(p.w);
+      int pos = i;
+      if (m > n) {                                   // overflow: rank by face index
+        pos = 0;
+        for (int k = 0; k < m; ++k) pos += __float_as_int(pp[k].w) < face;
+        if (pos >= n) continue;
+      }
+      // the reference keeps slots with collision_faces > 0 (:161): it drops face 0 as well
+      // as the empty (-1) slots
+      if (face > 0) { px[base + pos] = p.x; py[base + pos] = p.y; pz[base + pos] = p.z; }
     }
-    px[i] = x; py[i] = y; pz[i] = z;
   }
   __syncthreads();
-  // bitonic sort by (x, z, y): invalid (+inf) entries sink to the end; order is a pure
-  // function of the point set, so the atomics above do not make the result nondeterministic
+  // bitonic sort by (x, z, y): invalid (+inf) entries sink to the end
   for (int k = 2; k <= npow; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < npow; i += 256) {
+      for (int i = lane; i < npow; i += 64) {
         const int l = i ^ j;
         if (l > i) {
           const bool up = (i & k) == 0;
@@ -216,12 +298,11 @@ __global__ __launch_bounds__(256) void measure_hull_kernel(
       }
       __syncthreads();
     }
-  if (tid == 0) {
+  if (lane == 0) {
     int n = 0;
     while (n < npow && px[n] != INFINITY) ++n;
     float perim = 0.f;
     if (n >= 2) {
-      // Andrew's monotone chain in the (x, z) plane; exact orientation in float64
       auto orient = [&](int o, int a, int c) -> double {
         return ((double)px[a] - (double)px[o]) * ((double)pz[c] - (double)pz[o]) -
                ((double)pz[a] - (double)pz[o]) * ((double)px[c] - (double)px[o]);
@@ -246,10 +327,11 @@ __global__ __launch_bounds__(256) void measure_hull_kernel(
     out[b * 5 + 2 + pl] = perim;
     if (pl == 0) {
       double vs = 0.0;
-      for (int i = 0; i < n_vol_blocks; ++i) vs += (double)vol_partial[(long)b * n_vol_blocks + i];
+      for (int i = 0; i < n_slices; ++i) vs += (double)vol_partial[(long)b * n_slices + i];
       out[b * 5 + 0] = (float)(fabs(vs) / 6.0) * 985.0f;   // DENSITY (body_measurements.py:20)
       const float *vb = v_shaped + (long)b * V * 3;
-      const float head = lm_coord(vb, faces, lm, 0, 1), heel = lm_coord(vb, faces, lm, 1, 1);
+      auto vtx = [&](int idx, int c) -> float { return vb[(long)idx * 3 + c]; };
+      const float head = lm_coord(vtx, faces, lm, 0, 1), heel = lm_coord(vtx, faces, lm, 1, 1);
       out[b * 5 + 1] = fabsf(head - heel);                  // compute_height (:182-199)
     }
   }
@@ -295,10 +377,14 @@ extern "C" int shapy_mesh_to_mesh_f32(const float *query, const float *target, i
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+static bool measure_staged(int V) {
+  return (size_t)V * 12 + 32 + M2_STATIC_LDS <= (size_t)M2_LDS_TOTAL;
+}
+
 extern "C" size_t shapy_body_measure_workspace_bytes(int B, int F, int max_coll) {
-  const size_t nblk = (F + SCAN_THREADS - 1) / SCAN_THREADS;
-  return align_up((size_t)B * 6 * sizeof(int), 256) + align_up((size_t)B * nblk * sizeof(float), 256) +
-         (size_t)B * 6 * max_coll * sizeof(float4);
+  return align_up((size_t)B * 6 * sizeof(int), 256) +
+         align_up((size_t)B * M2_MAX_SLICES * sizeof(float), 256) +
+         (size_t)B * 6 * 2 * max_coll * sizeof(float4);
 }
 
 extern "C" int shapy_body_measure_f32(const float *v_shaped, const int32_t *faces, int B, int V,
@@ -307,7 +393,8 @@ extern "C" int shapy_body_measure_f32(const float *v_shaped, const int32_t *face
                                       size_t workspace_bytes, int32_t *overflow_out, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   if (B <= 0) return SHAPY_OK;
-  if (max_coll <= 0 || 2 * max_coll > HULL_MAX || F <= 0) return SHAPY_EINVAL;
+  if (max_coll <= 0 || max_coll > 512 || F <= 0 || V <= 0 || (long)F * 4 >= 0x7fffffffL)
+    return SHAPY_EINVAL;
   if (workspace_bytes < shapy_body_measure_workspace_bytes(B, F, max_coll)) return SHAPY_EWORKSPACE;
   Landmarks lm;
   for (int i = 0; i < 5; ++i) {
@@ -315,19 +402,39 @@ extern "C" int shapy_body_measure_f32(const float *v_shaped, const int32_t *face
     lm.face[i] = lm_face_host[i];
     for (int k = 0; k < 3; ++k) lm.bc[i][k] = lm_bary_host[i * 3 + k];
   }
-  const int nblk = (F + SCAN_THREADS - 1) / SCAN_THREADS;
+  const int CAP = 2 * max_coll;
   char *w = (char *)workspace;
   int *counters = (int *)w;
   w += align_up((size_t)B * 6 * sizeof(int), 256);
   float *vol = (float *)w;
-  w += align_up((size_t)B * nblk * sizeof(float), 256);
+  w += align_up((size_t)B * M2_MAX_SLICES * sizeof(float), 256);
   float4 *pts = (float4 *)w;
   SHAPY_HIP_TRY(hipMemsetAsync(counters, 0, (size_t)B * 6 * sizeof(int), s));
   if (overflow_out) SHAPY_HIP_TRY(hipMemsetAsync(overflow_out, 0, sizeof(int32_t), s));
-  hipLaunchKernelGGL(measure_scan_kernel, dim3(nblk, B), dim3(SCAN_THREADS), 0, s, v_shaped, faces,
-                     V, F, max_coll, lm, counters, vol, pts);
+  int S = 1;
+  if (measure_staged(V)) {
+    const size_t dyn = (size_t)V * 12 + 32;
+    static bool attr_set = false;       // > 64 KB of dynamic LDS must be opted into once
+    if (!attr_set) {
+      SHAPY_HIP_TRY(hipFuncSetAttribute((const void *)measure_scan2_kernel<true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        M2_LDS_TOTAL - M2_STATIC_LDS));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(measure_scan2_kernel<true>, dim3(1, B), dim3(M2_THREADS), dyn, s, v_shaped,
+                       faces, V, F, F, CAP, lm, counters, vol, pts);
+  } else {
+    S = (F + 4095) / 4096;
+    if (S > M2_MAX_SLICES) S = M2_MAX_SLICES;
+    const int Fs = (F + S - 1) / S;
+    hipLaunchKernelGGL(measure_scan2_kernel<false>, dim3(S, B), dim3(M2_THREADS), 0, s, v_shaped,
+                       faces, V, F, Fs, CAP, lm, counters, vol, pts);
+  }
   SHAPY_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(measure_hull_kernel, dim3(3, B), dim3(256), 0, s, v_shaped, faces, V, max_coll,
-                     nblk, lm, counters, vol, pts, out, overflow_out);
+  int NP = 2;
+  while (NP < 2 * max_coll) NP <<= 1;
+  const size_t hull_lds = (size_t)(4 * NP + 1) * 4;
+  hipLaunchKernelGGL(measure_hull2_kernel, dim3(3, B), dim3(64), hull_lds, s, v_shaped, faces, V,
+                     max_coll, CAP, NP, S, lm, counters, vol, pts, out, overflow_out);
   return (int)hipGetLastError();
 }

@@ -66,23 +66,52 @@ class BodyMeasurements(nn.Module):
     def extra_repr(self):
         return f'Human Body Density: {self.DENSITY}'
 
-    def forward_vertices(self, v_shaped, faces_i32):
-        """v_shaped [B,V,3] f32, faces [F,3] int32 -> [B,5] (mass, height, chest, waist, hips)."""
+    def forward_vertices(self, v_shaped, faces_i32, landmarks=None, max_collisions=None):
+        """v_shaped [B,V,3] f32, faces [F,3] int32 -> [B,5] (mass, height, chest, waist, hips).
+
+        ``landmarks``: optional ``(face_idx[5], bary[5][3])`` in the order HeadTop, HeelLeft,
+        chest, waist, hips replacing the SMPL-X definitions of the config (other topologies).
+        The number of plane/triangle hits dropped because a plane triangle collected more than
+        ``max_collisions`` is left in ``last_overflow`` (device tensor, no sync here);
+        ``check_overflow()`` reads it."""
         _lib.require_cuda(v_shaped, 'v_shaped')
         lib = _lib.load()
         v = v_shaped.contiguous().float()
         B, V = v.shape[:2]
         F = faces_i32.shape[0]
-        nbytes = lib.shapy_body_measure_workspace_bytes(B, F, self.max_collisions)
+        mc = int(max_collisions or self.max_collisions)
+        lm_face, lm_bc = self._lm_face, self._lm_bc
+        if landmarks is not None:
+            lm_face = (ctypes.c_int32 * 5)(*[int(i) for i in landmarks[0]])
+            lm_bc = (ctypes.c_float * 15)(*[np.float32(x) for bc in landmarks[1] for x in bc])
+        nbytes = lib.shapy_body_measure_workspace_bytes(B, F, mc)
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=v.device)
         out = torch.empty(B, 5, dtype=torch.float32, device=v.device)
         overflow = torch.zeros(1, dtype=torch.int32, device=v.device)
         _lib.check(lib.shapy_body_measure_f32(
-            _lib.ptr(v), _lib.ptr(faces_i32), B, V, F, self._lm_face, self._lm_bc,
-            self.max_collisions, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.ptr(overflow),
+            _lib.ptr(v), _lib.ptr(faces_i32.contiguous()), B, V, F, lm_face, lm_bc,
+            mc, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.ptr(overflow),
             _lib.current_stream()), 'shapy_body_measure_f32')
         self.last_overflow = overflow
         return out
+
+    def check_overflow(self, raise_error=False):
+        """Synchronising check of the last call: number of plane/triangle hits beyond
+        ``max_collisions`` (0 for every body-shaped mesh).  A truncated circumference is kept
+        deterministic (the lowest face indices win, as in the ascending-order oracle) but it is
+        not the circumference of the full cross-section: warn (or raise)."""
+        if self.last_overflow is None:
+            return 0
+        n = int(self.last_overflow.item())
+        if n > 0:
+            msg = (f'BodyMeasurements: {n} plane/triangle intersections exceeded '
+                   f'max_collisions={self.max_collisions}; chest/waist/hips are computed from a '
+                   'truncated point set -- raise max_collisions')
+            if raise_error:
+                raise RuntimeError(msg)
+            import warnings
+            warnings.warn(msg)
+        return n
 
     def _result(self, out, flags):
         meas = {}

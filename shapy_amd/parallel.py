@@ -5,7 +5,8 @@ buffers (65 MB) are replicated, so the forward pass needs NO exchange: every ran
 process per GPU) runs a contiguous shard of the batch.  The only collective is the
 all-gather of the predicted betas ([B_local, 10] float32 = 1,280 B per rank at bs=256/8)
 at the end of a step -- latency-bound, so it is issued as ONE RCCL all_gather on a side
-stream and overlaps the tail of the step (the measurement kernels).
+stream and joined into the compute stream only when the NEXT step issues its own gather
+(``BetasGatherer``): it overlaps the next batch's backbone.
 
 The reference has no data-parallel inference at all (rank > 0 returns immediately in its
 evaluator, regressor/human_shape/evaluation.py:641-642; the only collective it executes is
@@ -33,31 +34,68 @@ def init_distributed(backend='nccl'):
 
 
 class BetasGatherer:
-    """all_gather of equally sized per-rank tensors, issued on a side stream on GPUs."""
+    """all_gather of equally sized per-rank tensors on a side stream, DEFERRED: the current
+    stream does not wait for the collective when it is issued, so the (latency-bound) RCCL
+    call overlaps whatever the caller enqueues next -- in ``bench.py`` the backbone of the
+    next batch.
+
+        g = BetasGatherer(world)
+        for batch in batches:
+            prev = g(betas_of(batch))     # issues this step's gather; the tensor returned by
+                                          # the PREVIOUS call is complete from here on
+        last = g.wait()                   # joins the last gather into the current stream
+
+    ``gather(local)`` = issue + wait for callers that need the result right away.  On CPU
+    tensors (gloo) the collective is synchronous and every form returns a finished tensor."""
 
     def __init__(self, world=None, group=None):
         self.group = group
         self.world = world if world is not None else (
             dist.get_world_size(group) if dist.is_initialized() else 1)
         self._stream = None
+        self._pending = None          # (out, event) of the gather still in flight
+        self.issued = 0
+        self.deferred_waits = 0       # waits that were served by a LATER call (the overlap)
+
+    def wait(self):
+        """Makes the current stream wait for the gather in flight (if any); returns its result."""
+        if self._pending is None:
+            return None
+        out, ev = self._pending
+        self._pending = None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        return out
 
     def __call__(self, local):
         if self.world == 1:
             return local
+        if self._pending is not None:
+            self.deferred_waits += 1
+            self.wait()
         local = local.contiguous()
         out = local.new_empty((self.world * local.shape[0],) + tuple(local.shape[1:]))
+        self.issued += 1
         if local.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
-            cur = torch.cuda.current_stream()
-            self._stream.wait_stream(cur)
+            self._stream.wait_stream(torch.cuda.current_stream())    # `local` is produced there
             with torch.cuda.stream(self._stream):
                 dist.all_gather_into_tensor(out, local, group=self.group)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
             local.record_stream(self._stream)
-            cur.wait_stream(self._stream)
+            out.record_stream(self._stream)
+            self._pending = (out, ev)
         else:
             chunks = list(out.chunk(self.world, dim=0))
             dist.all_gather(chunks, local, group=self.group)
+            self._pending = (out, None)
+        return out
+
+    def gather(self, local):
+        out = self(local)
+        self.wait()
         return out
 
 

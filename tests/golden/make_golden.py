@@ -121,7 +121,7 @@ def main():
     betas = r.standard_normal((B, 10)).astype(np.float32)
     ident6 = np.tile(np.array([1, 0, 0, 1, 0, 0], np.float32), 22)
     pose6 = (ident6[None] + 0.3 * r.standard_normal((B, 132))).astype(np.float32)
-    # make one body turn its head far enough to exercise the dynamic-landmark LUT clamp
+    # (the dynamic-landmark LUT clamp has its own vectors: make_golden_lut.py)
     rot = ns.pose_utils.ContinuousRotReprDecoder(22)(torch.from_numpy(pose6))
     og['smplx_betas'] = betas
     og['smplx_pose6d'] = pose6

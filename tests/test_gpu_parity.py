@@ -504,3 +504,241 @@ def test_mesh_to_mesh_bvh_path_bit_exact_vs_oracle():
     torch.cuda.synchronize()
     assert np.array_equal(f.cpu().numpy(), f_ref)
     assert np.array_equal(b.cpu().numpy(), b_ref)
+
+
+# ------------------------------------------------------------------------------------------
+# round 2: the headline configuration at its own size, config 4 mesh by mesh, edge cases
+# ------------------------------------------------------------------------------------------
+_BS64 = {}
+
+
+def _oracle_bs64():
+    """CPU oracle on the bench's own batch (64 seeded 224x224 images); ~10 s, computed once."""
+    if not _BS64:
+        import __graft_entry__ as ge
+        from shapy_amd.utils import synthetic as syn
+        x = syn.synthetic_images(64, 224, 100)
+        _BS64['x'] = x
+        _BS64['ref'] = ge.oracle_forward(x)
+    return _BS64['x'], _BS64['ref']
+
+
+@pytest.mark.parametrize('cdt', ['f32', 'f32x6'])
+def test_full_forward_bs64_vs_oracle(network, cdt):
+    """BASELINE configs[1] at ITS OWN size: B = 64 @224, four streams on the liveness-packed
+    arena, the tile instantiations the dispatcher picks at this M.  features / betas /
+    vertices / joints / measurements against the CPU oracle at 1e-4."""
+    x_np, ref = _oracle_bs64()
+    x = torch.from_numpy(x_np).cuda()
+    network.backbone.multi_stream = True
+    network.backbone.compute_dtype = cdt
+    try:
+        with torch.no_grad():
+            out = network(x, None)
+        torch.cuda.synchronize()
+    finally:
+        network.backbone.compute_dtype = 'f32'
+    st, rs = out['stage_02'], ref['stages'][-1]
+    errs = {
+        'features': np.abs(out['features'].cpu().numpy() - ref['features']).max(),
+        'betas': np.abs(st['betas'].cpu().numpy() - rs['betas']).max(),
+        'vertices': np.abs(st['vertices'].cpu().numpy() - rs['vertices']).max(),
+        'v_shaped': np.abs(st['v_shaped'].cpu().numpy() - rs['v_shaped']).max(),
+        'joints': np.abs(st['joints']._t.cpu().numpy() - rs['joints']).max(),
+    }
+    for k in ('mass', 'height', 'chest', 'waist', 'hips'):
+        errs['meas_' + k] = np.abs(out['measurements'][k].cpu().numpy() - ref['measurements'][k]).max()
+    for k, v in errs.items():
+        print(f'bs64 {cdt} {k:14s} {v:.3e}')
+    assert int(network.body_measurements.last_overflow.item()) == 0
+    bad = {k: v for k, v in errs.items() if not v < (2e-4 if k == 'meas_mass' else 1e-4)}
+    assert not bad, bad
+
+
+def test_smplx_dynamic_landmark_lut_clamp_vs_reference_golden(network, golden_dir):
+    """Head yaw through and beyond the 39-degree clamp of the contour-landmark LUT
+    (lbs.py:35-42; tests/golden/make_golden_lut.py ran the REAL reference SMPLX.forward)."""
+    g = np.load(osp.join(golden_dir, 'ops_golden_lut.npz'))
+    rot = torch.from_numpy(g['rot']).cuda()
+    with torch.no_grad():
+        so = network.model(global_rot=rot[:, :1], body_pose=rot[:, 1:],
+                           betas=torch.from_numpy(g['betas']).cuda(), get_skin=True,
+                           return_shaped=True)
+    torch.cuda.synchronize()
+    ej = np.abs(so['joints']._t.cpu().numpy() - g['joints']).max(axis=(1, 2))
+    ev = np.abs(so['vertices'].cpu().numpy()[:, ::SUB] - g['vertices_sub']).max()
+    print('LUT rows', g['lut_rows'], 'joint err per body', ej, 'vertices', ev)
+    assert ej.max() < 1e-4 and ev < 1e-4
+
+
+def test_measurements_1000_meshes_vs_oracle(network):
+    """BASELINE configs[3] mesh by mesh: all 1,000 meshes against the C oracle + scipy hull."""
+    import bench
+    from oracle import measure as om
+    faces, v_np = bench.config4_meshes(1000, seed=0)
+    lm = om.load_landmarks(osp.join(DATA, 'measurement_defitions.yaml'),
+                           osp.join(DATA, 'smplx_measurements.yaml'))
+    ref = om.body_measurements(v_np[:, faces], lm)
+    bm = network.body_measurements
+    out = bm.forward_vertices(torch.from_numpy(v_np).cuda(), torch.from_numpy(faces).cuda())
+    out = out.cpu().numpy()
+    assert bm.check_overflow() == 0
+    for i, k in enumerate(('mass', 'height', 'chest', 'waist', 'hips')):
+        err = np.abs(out[:, i] - ref[k])
+        print(f'config4 {k:7s} max err {err.max():.3e} (mesh {err.argmax()})')
+        np.testing.assert_allclose(out[:, i], ref[k], rtol=5e-6 if k != 'mass' else 2e-5,
+                                   atol=2e-6, err_msg=k)
+    assert abs(out[0, 2] - 0.8745367) < 2e-6      # mesh 0 is the shipped sample
+
+
+def _prism(K, radius, y0, y1, jitter=None):
+    """Open K-sided prism around the y axis: 2K side triangles (vertices 0..2K-1)."""
+    ang = 2 * np.pi * np.arange(K) / K
+    r = np.full(K, radius, np.float64) if jitter is None else radius * (1 + jitter)
+    bot = np.stack([r * np.cos(ang), np.full(K, y0), r * np.sin(ang)], 1)
+    top = np.stack([r * np.cos(ang), np.full(K, y1), r * np.sin(ang)], 1)
+    v = np.concatenate([bot, top]).astype(np.float32)
+    f = []
+    for i in range(K):
+        j = (i + 1) % K
+        f += [[i, j, K + j], [i, K + j, K + i]]
+    return v, np.asarray(f, np.int32)
+
+
+def _with_landmarks(v, f, heights):
+    """Prepends 5 tiny landmark triangles (faces 0..4: head, heel, chest, waist, hips) far away
+    from the planes' cross-sections (x = 5: outside the [-1,1] plane quad)."""
+    lv, lf = [], []
+    for i, h in enumerate(heights):
+        lv += [[5.0, h, 5.0], [5.1, h, 5.0], [5.0, h, 5.1]]
+        lf.append([3 * i, 3 * i + 1, 3 * i + 2])
+    lv = np.asarray(lv, np.float32)
+    v2 = np.concatenate([lv, v]).astype(np.float32)
+    f2 = np.concatenate([np.asarray(lf, np.int32), f + len(lv)]).astype(np.int32)
+    lm = ([0, 1, 2, 3, 4], [[1 / 3, 1 / 3, 1 / 3]] * 5)
+    return v2, f2, lm
+
+
+def _oracle_lm(lm):
+    names = ('head_top', 'left_heel', 'chest', 'waist', 'hips')
+    return {n: (int(lm[0][i]), np.asarray(lm[1][i], np.float32)) for i, n in enumerate(names)}
+
+
+def test_hull_edge_cases_vs_oracle(network):
+    """Duplicate points, max_collisions overflow (lowest faces kept, as in the ascending-order
+    oracle), the reference's `collision_faces > 0` rule (face 0 dropped,
+    body_measurements.py:161), and the inputs on which the reference itself raises
+    (fewer than 3 points / collinear points: scipy QhullError) -> documented values."""
+    from oracle import measure as om
+    from scipy.spatial import QhullError
+    bm = network.body_measurements
+    r = np.random.default_rng(5)
+    heights = [0.9, -0.9, 0.31, 0.02, -0.37]          # head, heel, chest, waist, hips
+
+    def run(v, f, lm, mc):
+        out = bm.forward_vertices(torch.from_numpy(v[None]).cuda(), torch.from_numpy(f).cuda(),
+                                  landmarks=lm, max_collisions=mc).cpu().numpy()[0]
+        return out, int(bm.last_overflow.item())
+
+    # (1) jittered 40-gon, every triangle twice (exact duplicate points), no overflow
+    v, f = _prism(40, 0.4, -0.8, 0.8, jitter=0.2 * r.uniform(-1, 1, 40))
+    v, f, lm = _with_landmarks(v, np.concatenate([f, f]), heights)
+    ref = om.body_measurements(v[None][:, f], _oracle_lm(lm), max_collisions=256)
+    out, ov = run(v, f, lm, 256)
+    assert ov == 0 and om.mesh_to_mesh_forward.last_dropped == 0
+    for i, k in enumerate(('height', 'chest', 'waist', 'hips'), start=1):
+        assert abs(out[i] - ref[k][0]) < 2e-6, (k, out[i], ref[k][0])
+    # (2) the same mesh with max_collisions = 16: 160 hits per plane, the 16 lowest faces of each
+    # plane triangle survive in the oracle and on the GPU alike; the excess is reported
+    ref16 = om.body_measurements(v[None][:, f], _oracle_lm(lm), max_collisions=16)
+    dropped = 0
+    for h in heights[2:]:
+        om.mesh_to_mesh_forward(om.plane_triangles(np.float32([h])), v[None][:, f], 16)
+        dropped += om.mesh_to_mesh_forward.last_dropped
+    assert dropped > 100
+    out16, ov16 = run(v, f, lm, 16)
+    assert ov16 == dropped
+    for i, k in enumerate(('chest', 'waist', 'hips'), start=2):
+        assert abs(out16[i] - ref16[k][0]) < 2e-6, (k, out16[i], ref16[k][0])
+        assert abs(out16[i] - out[i]) > 1e-3            # truncated: a different polygon
+    with pytest.warns(UserWarning):
+        assert bm.check_overflow() == ov16
+    # (3) face 0 is dropped: make face 0 a big triangle through all three planes (the head
+    # landmark moves to the end of the table); with it the hull would be much larger
+    v3_, f3_ = _prism(24, 0.3, -0.8, 0.8)
+    v3_, f3_, lm3 = _with_landmarks(v3_, f3_, heights)
+    big = np.asarray([[-0.9, -0.85, -0.9], [0.9, 0.0, 0.9], [-0.9, 0.85, 0.9]], np.float32)
+    nv = len(v3_)
+    v3b = np.concatenate([v3_, big]).astype(np.float32)
+    f3b = np.concatenate([[[nv, nv + 1, nv + 2]], f3_[1:], f3_[:1]]).astype(np.int32)
+    lm3b = ([len(f3b) - 1, 1, 2, 3, 4], lm3[1])
+    ref3 = om.body_measurements(v3b[None][:, f3b], _oracle_lm(lm3b))
+    out3, _ = run(v3b, f3b, lm3b, 256)
+    base3, _ = run(v3_, f3_, lm3, 256)
+    for i, k in enumerate(('chest', 'waist', 'hips'), start=2):
+        assert abs(out3[i] - ref3[k][0]) < 2e-6, k
+        assert abs(out3[i] - base3[i]) < 2e-6, k       # as if the big triangle were not there
+    # (4) the reference raises on degenerate cross-sections; the kernel returns 0 for fewer
+    # than 2 points and twice the segment length for collinear points
+    flat_v = np.asarray([[-0.5, -0.8, 0.0], [0.5, -0.8, 0.0], [0.5, 0.8, 0.0], [-0.5, 0.8, 0.0]],
+                        np.float32)
+    flat_f = np.asarray([[0, 1, 2], [0, 2, 3]], np.int32)
+    v4, f4, lm4 = _with_landmarks(flat_v, flat_f, heights)
+    with pytest.raises(QhullError):
+        om.body_measurements(v4[None][:, f4], _oracle_lm(lm4))
+    out4, _ = run(v4, f4, lm4, 256)
+    for i in (2, 3, 4):
+        assert 0.0 < out4[i] <= 2.0 + 1e-5 and np.isfinite(out4[i])
+    v5, f5, lm5 = _with_landmarks(flat_v[:3] + np.float32([0, 5, 0]), flat_f[:1], heights)
+    out5, _ = run(v5, f5, lm5, 256)                    # nothing crosses any plane
+    assert out5[2] == 0 and out5[3] == 0 and out5[4] == 0
+    assert abs(out5[1] - 1.8) < 1e-6
+
+
+def _nccl_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from shapy_amd import parallel
+    from shapy_amd.utils import synthetic as syn
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', init_method='env://')
+    try:
+        net, _ = ge.make_network(model_folder=f'/tmp/shapy_synth_models_nccl{rank}')
+        xs = [torch.from_numpy(syn.synthetic_images(2, 64, 100 + r)).cuda() for r in range(world)]
+        gat = parallel.BetasGatherer(world)
+        with torch.no_grad():
+            mine = net(xs[rank], None)['stage_02']['betas']
+            g1 = gat(mine)
+            g2 = gat(mine + 1)                  # second step: joins the first gather
+            gat.wait()
+            others = torch.cat([net(x, None)['stage_02']['betas'] for x in xs])
+        torch.cuda.synchronize()
+        ok = (torch.equal(g1, others) and torch.equal(g2, others + 1) and gat.deferred_waits == 1)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_allgather_two_ranks():
+    """The N > 1 path on real RCCL: two ranks, one GPU each; every rank's gathered betas equal
+    what it computes itself for all shards (same weights, deterministic kernels)."""
+    _need_gpu()
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

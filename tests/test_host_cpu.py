@@ -203,8 +203,12 @@ def _dp_worker(rank, world, port, q):
     full = torch.arange(n * 10, dtype=torch.float32).view(n, 10)
     g = parallel.gather_variable(full[a:b])
     ok1 = torch.equal(g, full)
-    eq = parallel.BetasGatherer(w)(full[r * 3:(r + 1) * 3])
-    ok2 = torch.equal(eq, full[:6])
+    gat = parallel.BetasGatherer(w)
+    outs = [gat(full[r * 3:(r + 1) * 3] + k) for k in range(3)]      # three "steps"
+    last = gat.wait()
+    ok2 = (all(torch.equal(o, full[:6] + k) for k, o in enumerate(outs)) and last is outs[-1]
+           and gat.wait() is None and gat.issued == 3 and gat.deferred_waits == 2
+           and torch.equal(gat.gather(full[r * 3:(r + 1) * 3]), full[:6]))
     q.put((rank, ok1, ok2, (a, b)))
     dist.destroy_process_group()
 

@@ -82,6 +82,19 @@ def test_smplx_forward(golden_dir, synth_smplx):
     assert np.abs(proj - g['cam_proj']).max() < 5e-5
 
 
+def test_smplx_dynamic_landmark_lut_clamp(golden_dir, synth_smplx):
+    """Head yaw through / beyond the 39-degree clamp of the contour-landmark LUT (lbs.py:35-42),
+    both signs, incl. the half-to-even rounding next to it (make_golden_lut.py)."""
+    g = load(golden_dir, 'ops_golden_lut.npz')
+    assert sorted(set(g['lut_rows'])) == [0, 25, 39, 64, 77, 78]
+    rot = g['rot']
+    out = body_np.smplx_forward(synth_smplx, rot[:, :1], rot[:, 1:], g['betas'])
+    assert np.abs(out['joints'] - g['joints']).max() < 2e-5
+    assert np.abs(out['vertices'][:, ::SUB] - g['vertices_sub']).max() < 2e-5
+    # the 17 contour landmarks (last 17 joints) differ between LUT rows by far more than that
+    assert np.abs(g['joints'][3, -17:] - g['joints'][0, -17:]).max() > 1e-2
+
+
 # ---- HRNet + full regressor ------------------------------------------------------------
 @pytest.fixture(scope='module')
 def hrnet_sd():
