@@ -97,6 +97,13 @@ typedef struct ShapyConv {
   int32_t tile;       /* 0 = choose automatically; else a SHAPY_TILE_* id (bench/tuning)   */
   int32_t dtype;      /* storage type of in / wgt / res / out: SHAPY_DTYPE_F32 (f32 MFMA, exact
                          f32) or SHAPY_DTYPE_BF16 (bf16 MFMA, f32 accumulate; Cin % 32 == 0)  */
+  int32_t reserved0;
+  const void *wgt_wino; /* NULL, or the Winograd F(2x2,3x3) transform of wgt for a float32
+                         3x3 / stride 1 / pad 1 layer: U[p = 4i+j][Cin/16][Cout][16] float32,
+                         U[i][j] = (G g G^T)[i][j] (shapy_amd/utils/winograd.py).  When given
+                         (and Cin % 16 == 0, Cout % 48 == 0, 16-byte aligned out / res / bias
+                         rows) the layer runs on csrc/conv_wino.hip: 2.25x fewer MFMAs, result
+                         equal to the direct sum up to float32 rounding of the transforms.   */
 } ShapyConv;
 
 int shapy_conv2d(const ShapyConv *desc_host, void *stream);
@@ -117,6 +124,8 @@ typedef struct ShapyOp {
   int64_t in_off, out_off, res_off;     /* per-image float offsets into the workspace; -1 = none;
                                             in_off == -2: the network input (STEM)           */
   int64_t wgt_off, bias_off;            /* float offsets into the weight blob; -1 = none     */
+  int64_t wino_off;                     /* float offset of the Winograd-transformed filters
+                                           (ShapyConv.wgt_wino) in the blob; -1 = none        */
 } ShapyOp;
 
 /* input: [B,3,H,W] NCHW f32 (the reference's layout, iterative_regressor.py:623);

@@ -29,7 +29,8 @@ class ShapyConv(ctypes.Structure):
                 ('Ho', i32), ('Wo', i32), ('Cout', i32),
                 ('ksize', i32), ('stride', i32), ('pad', i32),
                 ('out_ld', i32), ('out_coff', i32), ('res_ld', i32), ('res_coff', i32),
-                ('relu', i32), ('ups', i32), ('tile', i32), ('dtype', i32)]
+                ('relu', i32), ('ups', i32), ('tile', i32), ('dtype', i32),
+                ('reserved0', i32), ('wgt_wino', vp)]
 
 
 class ShapyOp(ctypes.Structure):
@@ -39,7 +40,7 @@ class ShapyOp(ctypes.Structure):
                 ('out_ld', i32), ('out_coff', i32), ('res_ld', i32), ('res_coff', i32),
                 ('relu', i32), ('ups', i32), ('tile', i32),
                 ('in_off', i64), ('out_off', i64), ('res_off', i64),
-                ('wgt_off', i64), ('bias_off', i64)]
+                ('wgt_off', i64), ('bias_off', i64), ('wino_off', i64)]
 
 
 class ShapySmplxModel(ctypes.Structure):
@@ -61,6 +62,7 @@ for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: con
     TILES[_k + '+bk32'] = _v | 0x200
     TILES[_k + '+bk16'] = _v | 0x800
     TILES[_k + '+noswz+bk16'] = _v | 0xC00
+    TILES[_k + '+direct'] = _v | 0x2000       # never take the Winograd path
 
 #: every symbol include/shapy_hip.h declares: (restype, argtypes)
 SIGNATURES = {

@@ -19,6 +19,7 @@ ARCH = 'gfx950'
 SOURCES = {
     'conv_igemm.hip': [],
     'conv_x6.hip': [],
+    'conv_wino.hip': [],
     'hrnet_ops.hip': [],
     'body.hip': [],
     # bit-identical float32 decisions with the CPU oracle: no FMA contraction here

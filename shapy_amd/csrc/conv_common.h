@@ -39,7 +39,14 @@ struct ConvK {
   unsigned in_bytes, wgt_bytes;
   int Kp;                       // bf16x6 weights: K rounded up to 32 (row length of a plane)
   int vec4;                     // float32 out / res rows are 16-byte aligned: vector epilogue
+  const void *wgt2;             // Winograd-transformed filters [16][Cin/16][Cout][16] f32, or null
+  unsigned wgt2_bytes;
+  int wino_tiles;               // B * ceil(H/2) * ceil(W/2)
 };
+
+// Winograd F(2x2,3x3) path of the float32 3x3 / stride-1 layers (conv_wino.hip)
+bool conv_wino_eligible(const ConvK &k);
+int conv2d_wino(ConvK k, hipStream_t s);
 
 // float32 storage, bf16x6 split arithmetic on the bf16 matrix cores (conv_x6.hip)
 int conv2d_x6(const ConvK &k, int tile, hipStream_t s);

@@ -1,0 +1,251 @@
+// Winograd F(2x2, 3x3) convolution on the f32 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+// For the 3x3 / stride 1 / pad 1 layers of HighResolutionNet.forward
+// (regressor/human_shape/models/backbone/hrnet.py:175-193: both convs of every BasicBlock, 89 %
+// of the network's MACs) the minimal-filtering form
+//     Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A
+// needs 16 multiplies per 2x2 output tile and channel pair instead of 36: 2.25x fewer MFMAs
+// than the implicit GEMM of conv_igemm.hip, which is MFMA-throughput-bound on these layers.
+// All tensors stay float32; the transforms only add / subtract (and halve, in the filter
+// transform, which the host does in float64), so the result is float32-class: it differs from
+// the direct sum by a few ulp of the partial sums (parity tests: 1e-4 on the network output).
+//
+// GEMM view: 16 independent GEMMs (one per Winograd position p = 4 i + j), each
+// [tiles x Cin] x [Cin x Cout].  One 256-thread workgroup owns 16 consecutive tiles (2x2 output
+// pixels each, row-major over (b, ty, tx)) x N = 16 NN output channels:
+//   * staging: thread (tile, 4-channel group, patch row r) loads the 4 pixels of its patch row
+//     (buffer_load_dwordx4, out-of-image taps zeroed by the hardware bounds check), applies the
+//     row transform in registers, gets the rows it needs from its quad neighbours by DPP
+//     (V[i] = +-T[i] +- T[partner]) and writes V[p = 4 r + j][tile][16 ch] to LDS
+//     (16 KB per 16-channel chunk, XOR-swizzled 16-byte slots: conflict-free writes and reads);
+//   * wave w multiplies positions 4 w .. 4 w + 3 for all NN channel tiles: A fragments from LDS
+//     (one ds_read_b128 = the k-operands of 4 MFMAs, as in conv_igemm.hip), B fragments
+//     straight from the transformed filters in global memory (L2-resident, layout
+//     [p][Cin/16][Cout][16]: 1 KB contiguous per wave load; they are not shared between waves,
+//     so LDS would only add a round trip), prefetched one chunk ahead;
+//   * epilogue: the 16 positions of a (tile, channel) sit in 4 different waves: accumulators
+//     are parked in LDS (aliasing the staging buffer), then thread (tile, 4 channels) applies
+//     A^T . A, bias, residual, ReLU and stores 4 pixels x 16 bytes (whole 192-byte rows per
+//     pixel across the 12 threads of a tile).
+#include "conv_common.h"
+
+namespace shapy {
+
+__device__ __forceinline__ float quad_partner(float x) {
+  // lanes (0,1,2,3) of every quad read lanes (2,2,1,1): quad_perm = 2 | 2<<2 | 1<<4 | 1<<6
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x5A, 0xf, 0xf, true));
+}
+
+template <int NN>
+__global__ __launch_bounds__(256, 3) void conv_wino_kernel(ConvK p) {
+  constexpr int N = 16 * NN, NCP = N + 4, N4 = N / 4;
+  constexpr int LDS_V = 16 * 16 * 64;                 // V[16 pos][16 tiles][16 ch] f32
+  constexpr int LDS_X = 16 * 16 * NCP * 4;            // M[16 pos][16 tiles][N + 4] f32
+  __shared__ __attribute__((aligned(16))) char lds[LDS_X > LDS_V ? LDS_X : LDS_V];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wg = conv_tile_index(p);
+  const int m_blk = (wg / p.nbx) * 16, n_blk = (wg % p.nbx) * N;
+  const int H = p.Hi, W = p.Wi;
+  const int TW = (W + 1) >> 1, TH = (H + 1) >> 1;
+  const int T = p.wino_tiles;
+
+  const __amdgpu_buffer_rsrc_t rs_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_u =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt2), 0, p.wgt2_bytes, 0x00020000);
+  constexpr int OOB = 0x7fffffff;
+
+  // ---- staging role: (patch row r, tile, 4-channel group c4) ----
+  const int r = t & 3, c4 = (t >> 3) & 3, tile_s = ((t >> 5) << 1) | ((t >> 2) & 1);
+  int a_off;
+  bool xok[4], rowok;
+  {
+    const int tile = m_blk + tile_s;
+    const int tt = tile < T ? tile : 0;
+    const int tx = tt % TW;
+    const int tq = tt / TW;
+    const int ty = tq % TH;
+    const int b = tq / TH;
+    const int y = 2 * ty - 1 + r, x0 = 2 * tx - 1;
+    rowok = tile < T && (unsigned)y < (unsigned)H;
+    a_off = (((b * H + y) * W + x0) * p.in_ld + c4 * 4) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xok[k] = (unsigned)(x0 + k) < (unsigned)W;
+  }
+  const int pix_stride = p.in_ld * 4;
+  const float so = r == 3 ? -1.f : 1.f, sp = (r == 1 || r == 3) ? 1.f : -1.f;
+  const int fsw = (tile_s ^ (tile_s >> 1)) & 3;
+  const int st_off = tile_s * 64 + (((c4 ^ fsw ^ r) & 3) << 4) + 4 * r * 1024;   // + j * 1024
+
+  u32x4 raw[4];
+  // loads past the last chunk are issued with an out-of-range offset (they return 0 without
+  // touching memory): no branch around them, so the compiler's vmcnt counts stay exact
+  auto gload = [&](int c0, bool live) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      raw[k] = __builtin_amdgcn_raw_buffer_load_b128(
+          rs_in, (live && rowok && xok[k]) ? a_off + k * pix_stride + c0 * 4 : OOB, 0, 0);
+  };
+  auto lstore = [&]() {
+    f32x4 d[4], tr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = __builtin_bit_cast(f32x4, raw[k]);
+    tr[0] = d[0] - d[2];                  // T = d B   (columns of the patch row)
+    tr[1] = d[1] + d[2];
+    tr[2] = d[2] - d[1];
+    tr[3] = d[1] - d[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(sp, quad_partner(tr[j][e]), so * tr[j][e]);   // B^T T
+      *reinterpret_cast<f32x4 *>(lds + st_off + j * 1024) = v;
+    }
+  };
+
+  // ---- MFMA role: wave w owns positions 4 w + pp, all NN channel tiles ----
+  const int kq = lane >> 4, l15 = lane & 15;
+  const int frag_off = l15 * 64 + (((kq ^ ((l15 ^ (l15 >> 1)) & 3) ^ wave) & 3) << 4);
+  const int CC = p.Cin >> 4;
+  const int u_lane = ((n_blk + l15) * 16 + 4 * kq) * 4;
+  const int u_pos_stride = CC * p.Cout * 64, u_chunk_stride = p.Cout * 64;
+
+  u32x4 bfr[4][NN];
+  auto bload = [&](int pp, int cc, bool live) {
+    const int base = live ? u_lane + (4 * wave + pp) * u_pos_stride + cc * u_chunk_stride
+                          : OOB - 4096;
+#pragma unroll
+    for (int n = 0; n < NN; ++n)
+      bfr[pp][n] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, base + n * 1024, 0, 0);
+  };
+
+  f32x4 acc[4][NN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int n = 0; n < NN; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  gload(0, true);
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) bload(pp, 0, true);
+  lstore();
+  __syncthreads();
+
+  for (int cc = 0; cc < CC; ++cc) {
+    const bool more = cc + 1 < CC;
+    gload((cc + 1) * 16, more);
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const u32x4 af =
+          *reinterpret_cast<const u32x4 *>(lds + (4 * wave + pp) * 1024 + frag_off);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+          acc[pp][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+              __uint_as_float(af[kk]), __uint_as_float(bfr[pp][n][kk]), acc[pp][n], 0, 0, 0);
+      bload(pp, cc + 1, more);
+    }
+    __syncthreads();                         // everybody is done reading V
+    lstore();                                // (zeros after the last chunk: never read)
+    __syncthreads();
+  }
+
+  // ---- park the accumulators: M[p][tile][channel] ----
+  {
+    float *M = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+      for (int n = 0; n < NN; ++n)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          M[((4 * wave + pp) * 16 + 4 * kq + rg) * NCP + n * 16 + l15] = acc[pp][n][rg];
+  }
+  __syncthreads();
+
+  // ---- output transform + epilogue: thread (tile, 4 channels) ----
+  const float *res = reinterpret_cast<const float *>(p.res);
+  float *out = reinterpret_cast<float *>(p.out);
+  for (int it = t; it < 16 * N4; it += 256) {
+    const int c4o = it % N4, tl = it / N4;
+    const int tile = m_blk + tl;
+    if (tile >= T) continue;
+    const int col = n_blk + c4o * 4;
+    if (col >= p.Cout) continue;
+    const int tx = tile % TW;
+    const int tq = tile / TW;
+    const int ty = tq % TH;
+    const int b = tq / TH;
+    const float *Mp = reinterpret_cast<const float *>(lds) + tl * NCP + c4o * 4;
+    f32x4 tt[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 m0 = *reinterpret_cast<const f32x4 *>(Mp + (i * 4 + 0) * 16 * NCP);
+      const f32x4 m1 = *reinterpret_cast<const f32x4 *>(Mp + (i * 4 + 1) * 16 * NCP);
+      const f32x4 m2 = *reinterpret_cast<const f32x4 *>(Mp + (i * 4 + 2) * 16 * NCP);
+      const f32x4 m3 = *reinterpret_cast<const f32x4 *>(Mp + (i * 4 + 3) * 16 * NCP);
+      tt[i][0] = (m0 + m1) + m2;             // M A
+      tt[i][1] = (m1 - m2) - m3;
+    }
+    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias = *reinterpret_cast<const f32x4 *>(p.bias + col);
+    f32x4 y[2][2];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      y[0][bb] = ((tt[0][bb] + tt[1][bb]) + tt[2][bb]) + bias;      // A^T (M A)
+      y[1][bb] = ((tt[1][bb] - tt[2][bb]) - tt[3][bb]) + bias;
+    }
+    const int oy = 2 * ty, ox = 2 * tx;
+    bool ok[2][2];
+    long pix[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        ok[a][bb] = oy + a < H && ox + bb < W;
+        pix[a][bb] = ((long)(b * H + oy + a) * W + ox + bb);
+      }
+    if (res) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+          if (ok[a][bb])
+            y[a][bb] += *reinterpret_cast<const f32x4 *>(res + pix[a][bb] * p.res_ld + p.res_coff + col);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        if (!ok[a][bb]) continue;
+        f32x4 v = y[a][bb];
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<f32x4 *>(out + pix[a][bb] * p.out_ld + p.out_coff + col) = v;
+      }
+  }
+}
+
+bool conv_wino_eligible(const ConvK &k) {
+  return k.wgt2 != nullptr && k.ks == 3 && k.stride == 1 && k.pad == 1 && k.ups == 1 &&
+         k.Cin % 16 == 0 && k.Cout % 48 == 0 && k.vec4 && k.Ho == k.Hi && k.Wo == k.Wi &&
+         (!k.bias || ((uintptr_t)k.bias & 15) == 0);
+}
+
+int conv2d_wino(ConvK k, hipStream_t s) {
+  const int B = k.M / (k.Ho * k.Wo);
+  k.wino_tiles = B * ((k.Hi + 1) / 2) * ((k.Wi + 1) / 2);
+  const unsigned long long wb = 64ull * k.Cin * k.Cout;        // 16 positions x f32
+  if (wb >= 0x7fffffffull) return SHAPY_EINVAL;
+  k.wgt2_bytes = (unsigned)wb;
+  k.nbx = k.Cout / 48;
+  k.nby = (k.wino_tiles + 15) / 16;
+  hipLaunchKernelGGL((conv_wino_kernel<3>), dim3(k.nbx * k.nby), dim3(256), 0, s, k);
+  return (int)hipGetLastError();
+}
+
+}  // namespace shapy

@@ -166,6 +166,8 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
       d.Ho = o.Ho; d.Wo = o.Wo; d.Cout = o.Cout; d.ksize = o.ksize; d.stride = o.stride;
       d.pad = o.pad; d.out_ld = o.out_ld; d.out_coff = o.out_coff; d.res_ld = o.res_ld;
       d.res_coff = o.res_coff; d.relu = o.relu; d.ups = o.ups; d.tile = o.tile;
+      d.reserved0 = 0;
+      d.wgt_wino = (dtype == SHAPY_DTYPE_F32 && o.wino_off >= 0) ? wf32 + o.wino_off : nullptr;
       int rc = conv2d(d, s);
       if (rc) return rc;
     } else if (o.type == SHAPY_OP_STEM) {

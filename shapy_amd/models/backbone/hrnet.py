@@ -27,6 +27,8 @@ import torch
 import torch.nn as nn
 
 from ... import _lib
+from ...utils.versioning import VersionedWeights
+from ...utils import winograd
 
 BN_MOMENTUM = 0.1
 
@@ -279,7 +281,7 @@ def _fold(conv, bn):
     return w.float().numpy(), b.float().numpy()
 
 
-class HighResolutionNet(nn.Module):
+class HighResolutionNet(VersionedWeights, nn.Module):
 
     def __init__(self, cfg, **kwargs):
         super().__init__()
@@ -341,6 +343,14 @@ class HighResolutionNet(nn.Module):
         #: exact 3-way bf16 split on the bf16 matrix cores (float32-class accuracy);
         #: 'bf16' = bf16 weights/activations, f32 accumulate
         self.compute_dtype = 'f32'
+        #: float32 convolution algorithm of the 3x3 / stride-1 layers: 'direct' = implicit GEMM
+        #: for every layer (the exact-f32 fmaf chain); 'winograd' = Winograd F(2x2,3x3)
+        #: (csrc/conv_wino.hip, 2.25x fewer MFMAs, float32-class result) wherever the kernel
+        #: applies; 'auto' = Winograd on feature maps of at least wino_min_hw pixels a side
+        #: (small maps have too few tiles to fill the chip and pad 7 -> 8)
+        self.conv_algo = 'direct'
+        self.wino_min_hw = 14
+        self._engine_ver = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
 
     # ---- construction helpers (mirror hrnet.py:301-424) ----
@@ -436,21 +446,34 @@ class HighResolutionNet(nn.Module):
 
     # ---- engine ----
     def invalidate(self):
+        """Drops the folded weight blob, the op lists and the captured hipGraphs.  Called
+        automatically when a parameter / buffer version changes (``_compile``), after
+        ``load_state_dict`` and after ``.to()`` / ``.cuda()``."""
         self._engine = {}
+        self._drop_version_cache()
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._engine = {}
+        self._drop_version_cache()
         return out
 
     def __getstate__(self):
         st = self.__dict__.copy()
         st['_engine'] = {}
+        st['_ver_tensors'] = None
         return st
+
+    def _use_wino(self, ks, st, pad, cin, cout, Hi, Wi, ups):
+        if self.conv_algo == 'direct' or not winograd.eligible(ks, st, pad, cin, cout, ups):
+            return False
+        return self.conv_algo == 'winograd' or min(Hi, Wi) >= self.wino_min_hw
 
     def _build_plan(self, H, W, bf16=False, x6=False):
         P = _Plan(bf16, x6)
         ov = self.tile_overrides
+        if self.conv_algo not in ('direct', 'winograd', 'auto'):
+            raise ValueError(f'unknown conv_algo {self.conv_algo!r}')
 
         def conv(conv_m, bn, inb, Hi, Wi, outb=None, res=None, relu=False, ups=1, lane=0,
                  out_ld=None, out_coff=0, res_ld=None, res_coff=0, name=''):
@@ -468,12 +491,15 @@ class HighResolutionNet(nn.Module):
                 w, b = wp, bp
             if outb is None:
                 outb = P.buf(Ho * ups, Wo * ups, cout_p)
+            wino_off = -1
+            if not (bf16 or x6) and self._use_wino(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
+                wino_off = P.add_weights(winograd.transform_filters(w))
             P.op(type=_lib.OP_CONV, lane=lane, inb=inb, outb=outb, resb=res, Hi=Hi, Wi=Wi, Cin=cin_p,
                  in_ld=inb.C, Ho=Ho, Wo=Wo, Cout=cout_p, ksize=ks, stride=st, pad=pad,
                  out_ld=out_ld or outb.C, out_coff=out_coff,
                  res_ld=(res_ld or (res.C if res is not None else 0)), res_coff=res_coff,
                  relu=int(relu), ups=ups, tile=_lib.TILES[ov.get(name, 'auto')] | self.tile_flags,
-                 wgt_off=P.add_conv_weights(w), bias_off=P.add_weights(b))
+                 wgt_off=P.add_conv_weights(w), bias_off=P.add_weights(b), wino_off=wino_off)
             return outb, Ho, Wo
 
         # stem (hrnet.py:427-432)
@@ -483,7 +509,7 @@ class HighResolutionNet(nn.Module):
         P.op(type=_lib.OP_STEM, lane=0, inb=None, outb=s1, resb=None, Hi=H, Wi=W, Cin=3, in_ld=0,
              Ho=H1, Wo=W1, Cout=64, ksize=3, stride=2, pad=1, out_ld=64, out_coff=0, res_ld=0,
              res_coff=0, relu=1, ups=1, tile=0, wgt_off=P.add_weights(w.reshape(64, 27)),
-             bias_off=P.add_weights(b))      # the stem keeps float32 weights in both modes
+             bias_off=P.add_weights(b), wino_off=-1)   # the stem keeps float32 weights in both modes
         x, Hc, Wc = conv(self.conv2, self.bn2, s1, H1, W1, relu=True, name='conv2')
 
         def bottleneck(m, x, Hc, Wc, lane=0, side_lane=None, name=''):
@@ -618,14 +644,19 @@ class HighResolutionNet(nn.Module):
             P.barrier()
         P.op(type=_lib.OP_MEANPOOL, lane=0, inb=x, outb=None, resb=None, Hi=Hc, Wi=Wc, Cin=x.C,
              in_ld=x.C, Ho=1, Wo=1, Cout=x.C, ksize=1, stride=1, pad=0, out_ld=x.C, out_coff=0,
-             res_ld=0, res_coff=0, relu=0, ups=1, tile=0, wgt_off=-1, bias_off=-1)
+             res_ld=0, res_coff=0, relu=0, ups=1, tile=0, wgt_off=-1, bias_off=-1, wino_off=-1)
         return P
 
     def _compile(self, H, W, device):
         if self.compute_dtype not in ('f32', 'f32x6', 'bf16'):
             raise ValueError(f'unknown compute_dtype {self.compute_dtype!r}')
         bf16 = self.compute_dtype == 'bf16'
-        key = (H, W, str(device), self.compute_dtype)
+        ver = self._weights_version()
+        if ver != self._engine_ver:          # a parameter / buffer was edited in place
+            self._engine = {}
+            self._engine_ver = ver
+        key = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
+               self.tile_flags, tuple(sorted(self.tile_overrides.items())))
         eng = self._engine.get(key)
         if eng is not None:
             return eng
@@ -637,7 +668,7 @@ class HighResolutionNet(nn.Module):
             a = arr[i]
             for f in ('type', 'lane', 'barrier_before', 'Hi', 'Wi', 'Cin', 'in_ld', 'Ho', 'Wo',
                       'Cout', 'ksize', 'stride', 'pad', 'out_ld', 'out_coff', 'res_ld', 'res_coff',
-                      'relu', 'ups', 'tile', 'wgt_off', 'bias_off'):
+                      'relu', 'ups', 'tile', 'wgt_off', 'bias_off', 'wino_off'):
                 setattr(a, f, int(o[f]))
             a.in_off = -2 if o['type'] == _lib.OP_STEM else o['inb'].off
             a.out_off = -1 if o['outb'] is None else o['outb'].off

@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib
+from ...utils.versioning import VersionedWeights
 from ...utils.synthetic import keypoint_names as _smplx_keypoint_names
 from .utils import KeypointTensor, find_joint_kin_chain, to_tensor
 
@@ -45,7 +46,7 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
-class SMPLX(nn.Module):
+class SMPLX(VersionedWeights, nn.Module):
     NUM_BODY_JOINTS = 21
     NUM_HAND_JOINTS = 15
     NUM_FACE_JOINTS = 3
@@ -171,18 +172,25 @@ class SMPLX(nn.Module):
     # ---- device-side model ----
     def invalidate(self):
         self._dev = {}
+        self._drop_version_cache()
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._dev = {}
+        self._drop_version_cache()
         return out
 
     def __getstate__(self):
         st = self.__dict__.copy()
         st['_dev'] = {}
+        st['_ver_tensors'] = None
         return st
 
     def _device_model(self, device):
+        ver = self._weights_version()          # in-place edits of the model buffers
+        if ver != self.__dict__.get('_dev_ver'):
+            self._dev = {}
+            self.__dict__['_dev_ver'] = ver
         key = str(device)
         dm = self._dev.get(key)
         if dm is not None:

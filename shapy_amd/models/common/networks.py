@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib
+from ...utils.versioning import VersionedWeights
 
 
 def build_activation(activ_cfg):
@@ -105,7 +106,7 @@ class MLP(nn.Module):
         raise RuntimeError('MLP is evaluated inside IterativeRegression on the HIP path')
 
 
-class IterativeRegression(nn.Module):
+class IterativeRegression(VersionedWeights, nn.Module):
     def __init__(self, module, mean_param, num_stages=1, append_params=True, learn_mean=False,
                  detach_mean=False, dim=1, **kwargs):
         super().__init__()
@@ -131,18 +132,25 @@ class IterativeRegression(nn.Module):
 
     def invalidate(self):
         self._packed = {}
+        self._drop_version_cache()
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._packed = {}
+        self._drop_version_cache()
         return out
 
     def __getstate__(self):
         st = self.__dict__.copy()
         st['_packed'] = {}
+        st['_ver_tensors'] = None
         return st
 
     def _pack(self, device, F):
+        ver = self._weights_version()          # in-place edits of the Linear layers / mean
+        if ver != self.__dict__.get('_packed_ver'):
+            self._packed = {}
+            self.__dict__['_packed_ver'] = ver
         key = (str(device), F)
         pk = self._packed.get(key)
         if pk is None:

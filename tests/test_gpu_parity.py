@@ -32,7 +32,7 @@ def lib():
 
 
 def _conv_call(lib, x, w, b, res=None, relu=False, stride=1, pad=0, ups=1, tile=0, out=None,
-               out_ld=None, out_coff=0, x6=False):
+               out_ld=None, out_coff=0, x6=False, wino=False):
     """x [B,H,W,C] NHWC cuda, w [O,kh,kw,C] cuda -> out NHWC."""
     from shapy_amd import _lib
     B, Hi, Wi, C = x.shape
@@ -57,6 +57,10 @@ def _conv_call(lib, x, w, b, res=None, relu=False, stride=1, pad=0, ups=1, tile=
     d.out_ld = out_ld or O; d.out_coff = out_coff
     d.res_ld = (out_ld or O) if res is not None else 0; d.res_coff = out_coff if res is not None else 0
     d.relu = int(relu); d.ups = ups; d.tile = tile
+    if wino:                                           # Winograd-transformed filters as well
+        from shapy_amd.utils import winograd
+        wu = torch.from_numpy(winograd.transform_filters(w.cpu().numpy())).to(x.device)
+        d.wgt_wino = wu.data_ptr()
     rc = lib.shapy_conv2d(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
     torch.cuda.synchronize()
@@ -117,6 +121,62 @@ def test_conv_kernel_vs_float64(lib, case):
     ref = _conv_ref(x, w, b, res, relu, stride, pad, ups)
     err = (out.cpu().double() - ref).abs().max().item()
     assert err < 2e-5, err
+
+
+WINO_CASES = [
+    # B, H, W, Cin, Cout, res, relu
+    (1, 4, 4, 16, 48, False, False),       # 4 tiles: one partial workgroup, one K chunk
+    (2, 8, 8, 16, 48, False, False),
+    (1, 7, 7, 32, 96, True, False),        # odd size (masked last row / column), 2 N blocks
+    (3, 14, 14, 48, 48, True, True),       # the 56x56-branch layer class
+    (2, 5, 6, 16, 48, False, True),
+    (2, 28, 28, 96, 96, True, True),
+    (1, 14, 14, 192, 192, True, True),
+    (1, 7, 7, 384, 384, True, True),
+    (2, 56, 56, 48, 48, True, True),
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES, ids=[str(c) for c in WINO_CASES])
+def test_conv_winograd_kernel_vs_float64(lib, case):
+    """csrc/conv_wino.hip through shapy_conv2d (ShapyConv.wgt_wino) against float64, and
+    against the direct kernel on the same operands."""
+    B, H, W, Cin, Cout, use_res, relu = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / np.sqrt(9 * Cin)).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(B, H, W, Cout, generator=g).cuda() if use_res else None
+    out = _conv_call(lib, x, w, b, res, relu, 1, 1, wino=True)
+    direct = _conv_call(lib, x, w, b, res, relu, 1, 1, tile=0x2000, wino=True)   # forced direct
+    ref = _conv_ref(x, w, b, res, relu, 1, 1)
+    e = (out.cpu().double() - ref).abs()
+    ed = (direct.cpu().double() - ref).abs().max().item()
+    if not e.max().item() < 2e-5:           # localise: which pixels / channels are off
+        bad = (e > 2e-5)
+        print('bad fraction', bad.float().mean().item(), 'direct err', ed)
+        print('bad per row y:', bad.any(dim=3).any(dim=2).any(dim=0).int().tolist())
+        print('bad per col x:', bad.any(dim=3).any(dim=1).any(dim=0).int().tolist())
+        print('bad per channel:', bad.any(dim=2).any(dim=1).any(dim=0).int().tolist())
+        print('bad per image:', bad.any(dim=3).any(dim=2).any(dim=1).int().tolist())
+    assert ed < 2e-5, ed
+    assert e.max().item() < 2e-5, e.max().item()
+    assert not torch.equal(out, direct) or Cin * H * W < 300   # really a different algorithm
+
+
+def test_conv_winograd_concat_offset(lib):
+    """Winograd epilogue with out_ld > Cout / channel offset, in-place residual."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 10, 10, 32, generator=g).cuda()
+    w = (torch.randn(48, 3, 3, 32, generator=g) / 17).cuda()
+    b = torch.randn(48, generator=g).cuda()
+    big = torch.randn(2, 10, 10, 112, generator=g).cuda()
+    before = big.clone()
+    _conv_call(lib, x, w, b, res=big, relu=True, stride=1, pad=1, out=big, out_ld=112,
+               out_coff=16, wino=True)
+    ref = _conv_ref(x, w, b, before[..., 16:64], True, 1, 1)
+    assert (big[..., 16:64].cpu().double() - ref).abs().max().item() < 2e-5
+    assert torch.equal(big[..., :16], before[..., :16]) and torch.equal(big[..., 64:], before[..., 64:])
 
 
 X6_CASES = [c for c in CONV_CASES if c[10] in (0, 5, 8, 2, 6, 3, 7)] + [
@@ -243,6 +303,30 @@ def network():
     syn.fill_module_synthetic(net, 0)
     net = net.to('cuda').eval()
     return net
+
+
+@pytest.mark.parametrize('tag,b,s', [('b2_64', 2, 64), ('b3_96', 3, 96), ('b1_224', 1, 224)])
+@pytest.mark.parametrize('algo', ['winograd', 'auto'])
+def test_hrnet_winograd_features_vs_reference_golden(network, golden_dir, tag, b, s, algo):
+    """The float32 path with Winograd F(2x2,3x3) on the 3x3 / stride-1 layers against the
+    reference's CPU features at the north-star tolerance 1e-4."""
+    from shapy_amd.utils import synthetic as syn
+    g = np.load(osp.join(golden_dir, 'hrnet_golden.npz'))
+    x = torch.from_numpy(syn.synthetic_images(b, s, 0)).cuda()
+    network.backbone.multi_stream = True
+    network.backbone.conv_algo = algo
+    try:
+        with torch.no_grad():
+            feat = network.backbone(x)['concat']
+        torch.cuda.synchronize()
+        eng = [e for k, e in network.backbone._engine.items() if k[4] == algo][-1]
+        n_wino = sum(1 for o in eng['plan'].ops if o.get('wino_off', -1) >= 0)
+    finally:
+        network.backbone.conv_algo = 'direct'
+    err = np.abs(feat.cpu().numpy() - g[tag]).max()
+    print(tag, algo, 'winograd layers', n_wino, 'max abs err', err)
+    assert n_wino > (100 if algo == 'winograd' else 0)
+    assert err < 1e-4, err
 
 
 @pytest.mark.parametrize('tag,b,s', [('b2_64', 2, 64), ('b3_96', 3, 96), ('b1_224', 1, 224)])
@@ -523,7 +607,7 @@ def _oracle_bs64():
     return _BS64['x'], _BS64['ref']
 
 
-@pytest.mark.parametrize('cdt', ['f32', 'f32x6'])
+@pytest.mark.parametrize('cdt', ['f32', 'f32x6', 'f32+winograd'])
 def test_full_forward_bs64_vs_oracle(network, cdt):
     """BASELINE configs[1] at ITS OWN size: B = 64 @224, four streams on the liveness-packed
     arena, the tile instantiations the dispatcher picks at this M.  features / betas /
@@ -531,13 +615,15 @@ def test_full_forward_bs64_vs_oracle(network, cdt):
     x_np, ref = _oracle_bs64()
     x = torch.from_numpy(x_np).cuda()
     network.backbone.multi_stream = True
-    network.backbone.compute_dtype = cdt
+    network.backbone.compute_dtype = cdt.split('+')[0]
+    network.backbone.conv_algo = 'auto' if cdt.endswith('winograd') else 'direct'
     try:
         with torch.no_grad():
             out = network(x, None)
         torch.cuda.synchronize()
     finally:
         network.backbone.compute_dtype = 'f32'
+        network.backbone.conv_algo = 'direct'
     st, rs = out['stage_02'], ref['stages'][-1]
     errs = {
         'features': np.abs(out['features'].cpu().numpy() - ref['features']).max(),

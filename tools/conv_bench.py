@@ -1,6 +1,6 @@
 """Per-shape microbenchmark of the MFMA conv kernel over the conv classes of HRNet-W48.
 
-    python tools/conv_bench.py [--batch 64] [--size 224] [--tiles auto,256x48,...] [--out file]
+    python tools/conv_bench.py [--batch 64] [--size 224] [--tiles auto,wino,256x48,...] [--out file]
 
 For every distinct (Hi, Cin, Cout, ksize, stride, ups, residual) class of the backbone's op
 list it times shapy_conv2d alone on the GPU (HIP events, single stream) and prints
@@ -64,8 +64,16 @@ def main():
         out = torch.empty(B, Ho * ups, Wo * ups, Cout, device='cuda', dtype=tdt)
         res = torch.randn_like(out) if has_res else None
         flop = 2.0 * B * Ho * Wo * Cout * Cin * ks * ks
+        wu = None
         for tile in args.tiles.split(','):
             d = _lib.ShapyConv()
+            if tile == 'wino':                         # Winograd F(2x2,3x3) where it applies
+                from shapy_amd.utils import winograd
+                if args.dtype != 'f32' or not winograd.eligible(ks, st, pad, Cin, Cout, ups):
+                    continue
+                if wu is None:
+                    wu = torch.from_numpy(winograd.transform_filters(w.cpu().numpy())).cuda()
+                d.wgt_wino = wu.data_ptr()
             d.in_ = x.data_ptr(); d.wgt = w.data_ptr(); d.bias = b.data_ptr()
             d.res = res.data_ptr() if has_res else None
             d.out = out.data_ptr()
@@ -73,7 +81,7 @@ def main():
             d.Ho, d.Wo, d.Cout = Ho, Wo, Cout
             d.ksize, d.stride, d.pad = ks, st, pad
             d.out_ld = Cout; d.out_coff = 0; d.res_ld = Cout if has_res else 0; d.res_coff = 0
-            d.relu = int(relu); d.ups = ups; d.tile = _lib.TILES[tile]
+            d.relu = int(relu); d.ups = ups; d.tile = _lib.TILES['auto' if tile == 'wino' else tile]
             d.dtype = {'f32': _lib.DTYPE_F32, 'bf16': _lib.DTYPE_BF16, 'f32x6': _lib.DTYPE_F32X6}[args.dtype]
             rc = 0
             for _ in range(2):
