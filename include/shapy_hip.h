@@ -238,6 +238,14 @@ int shapy_smplx_joints_f32(const ShapySmplxModel *model_host, const float *posed
  * (the reference's is BVH traversal order, unspecified).  Hits beyond max_coll are dropped
  * and counted in *overflow_out (int32 device counter, may be NULL); the reference writes
  * out of bounds in that case (.cu:551,565).
+ * float32 ONLY -- a deliberate refusal, not an omission: the reference instantiates the operator
+ * for double as well (AT_DISPATCH_FLOATING_TYPES, .cu:996), but no caller in SHAPY ever passes
+ * float64 triangles (body_measurements.py:137-139 feeds float32 v_shaped), its predicates mix
+ * float constants into the double instantiation (FLT_EPSILON / fabsf in CMP, .cu:91-92; the
+ * 1e-4 determinant cut), so a float64 port would have to reproduce float-in-double quirks that
+ * nothing pins.  The Python operator raises NotImplementedError for float64 tensors
+ * (shapy_amd/measurements/mesh_mesh_intersection.py); callers holding float64 meshes convert
+ * with .float() exactly as BodyMeasurements' own inputs are.
  * ------------------------------------------------------------------------------------- */
 size_t shapy_mesh_to_mesh_workspace_bytes(int B, int Q, int F, int max_coll);
 int shapy_mesh_to_mesh_f32(const float *query, const float *target, int B, int Q, int F,

@@ -732,8 +732,10 @@ def test_hull_edge_cases_vs_oracle(network):
     ref = om.body_measurements(v[None][:, f], _oracle_lm(lm), max_collisions=256)
     out, ov = run(v, f, lm, 256)
     assert ov == 0 and om.mesh_to_mesh_forward.last_dropped == 0
+    # perimeters of O(3 m) summed over 40 float32 edges in a different order than Qhull's
+    # simplices: 4e-6 relative
     for i, k in enumerate(('height', 'chest', 'waist', 'hips'), start=1):
-        assert abs(out[i] - ref[k][0]) < 2e-6, (k, out[i], ref[k][0])
+        assert abs(out[i] - ref[k][0]) < 4e-6 * max(1.0, ref[k][0]), (k, out[i], ref[k][0])
     # (2) the same mesh with max_collisions = 16: 160 hits per plane, the 16 lowest faces of each
     # plane triangle survive in the oracle and on the GPU alike; the excess is reported
     ref16 = om.body_measurements(v[None][:, f], _oracle_lm(lm), max_collisions=16)
@@ -745,7 +747,7 @@ def test_hull_edge_cases_vs_oracle(network):
     out16, ov16 = run(v, f, lm, 16)
     assert ov16 == dropped
     for i, k in enumerate(('chest', 'waist', 'hips'), start=2):
-        assert abs(out16[i] - ref16[k][0]) < 2e-6, (k, out16[i], ref16[k][0])
+        assert abs(out16[i] - ref16[k][0]) < 4e-6 * max(1.0, ref16[k][0]), (k, out16[i], ref16[k][0])
         assert abs(out16[i] - out[i]) > 1e-3            # truncated: a different polygon
     with pytest.warns(UserWarning):
         assert bm.check_overflow() == ov16
@@ -762,8 +764,8 @@ def test_hull_edge_cases_vs_oracle(network):
     out3, _ = run(v3b, f3b, lm3b, 256)
     base3, _ = run(v3_, f3_, lm3, 256)
     for i, k in enumerate(('chest', 'waist', 'hips'), start=2):
-        assert abs(out3[i] - ref3[k][0]) < 2e-6, k
-        assert abs(out3[i] - base3[i]) < 2e-6, k       # as if the big triangle were not there
+        assert abs(out3[i] - ref3[k][0]) < 4e-6 * max(1.0, ref3[k][0]), k
+        assert abs(out3[i] - base3[i]) < 4e-6, k       # as if the big triangle were not there
     # (4) the reference raises on degenerate cross-sections; the kernel returns 0 for fewer
     # than 2 points and twice the segment length for collinear points
     flat_v = np.asarray([[-0.5, -0.8, 0.0], [0.5, -0.8, 0.0], [0.5, 0.8, 0.0], [-0.5, 0.8, 0.0]],

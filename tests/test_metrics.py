@@ -230,3 +230,55 @@ def test_evaluator_compute_metric_vs_oracle(inputs):
         ev.compute_metric(out, targets, {'mpjpe': {}})
     means = ev.reduce({k: [torch.from_numpy(v)] for k, v in got.items()})
     assert abs(means['mass'] - 2000.0) < 1e-2
+
+
+@gpu
+def test_evaluate_hbw_cli_vs_oracle(tmp_path, capsys):
+    """hbw_evaluation/evaluate_hbw.py (reference CLI, evaluate_hbw.py:61-187) on a synthetic
+    HBW tree: V2V / P2P-20k / measurement errors against the numpy + C oracle."""
+    import pickle
+    import scipy.sparse as sp
+    ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
+    sys.path.insert(0, osp.join(ROOT, 'hbw_evaluation'))
+    import evaluate_hbw as eh
+    from oracle import measure as om
+    from shapy_amd.utils import synthetic as syn
+    faces, meshes = syn.load_topology()
+    V = meshes.shape[1]
+    r = np.random.default_rng(3)
+    # ground truth: 3 subjects in two splits; 5 predictions (two images of one subject)
+    (tmp_path / 'hbw' / 'smplx' / 'val').mkdir(parents=True)
+    (tmp_path / 'hbw' / 'smplx' / 'test').mkdir(parents=True)
+    subj = {('val', '012'): meshes[0], ('val', '033'): 0.5 * (meshes[1] + meshes[2]),
+            ('test', '007'): 1.03 * meshes[3]}
+    for (split, sid), v in subj.items():
+        np.save(tmp_path / 'hbw' / 'smplx' / split / f'{sid}.npy', v.astype(np.float64))
+    labels = ['val/012_55/Photos/a.png', 'val/012_55/Photos/b.png', 'val/033_10/Photos/c.png',
+              'test/007_01/Photos/d.png', 'val/033_10/Photos/e.png']
+    gts = np.stack([subj[(l.split('/')[0], l.split('/')[1].split('_')[0])] for l in labels]).astype(np.float32)
+    fits = (gts * r.uniform(0.97, 1.03, (5, 1, 1)) + r.normal(0, 2e-3, gts.shape) +
+            r.normal(0, 0.05, (5, 1, 3))).astype(np.float32)
+    np.savez(tmp_path / 'pred.npz', image_name=np.array(labels), v_shaped=fits)
+    P = 500
+    rows = np.repeat(np.arange(P), 3)
+    reg = sp.csr_matrix((r.dirichlet(np.ones(3), P).reshape(-1), (rows, r.integers(0, V, 3 * P))),
+                        shape=(P, V))
+    with open(tmp_path / 'reg.pkl', 'wb') as f:
+        pickle.dump(reg, f)
+    (tmp_path / 'models' / 'smplx').mkdir(parents=True)
+    np.savez(tmp_path / 'models' / 'smplx' / 'SMPLX_NEUTRAL.npz', f=faces)
+    data = osp.join(ROOT, 'shapy_amd', 'data')
+    res = eh.main(str(tmp_path / 'pred.npz'), str(tmp_path / 'hbw'), 'smplx', str(tmp_path / 'reg.pkl'),
+                  str(tmp_path / 'reg.pkl'), data, str(tmp_path / 'models'))
+    printed = capsys.readouterr().out
+    assert 'V2V Error:' in printed and 'P2P-20k Error:' in printed and 'mass Error:' in printed
+    want_v2v = metrics_np.aligned_point_error(fits, gts, 'translation').mean(axis=1)
+    np.testing.assert_allclose(res['v2v'], want_v2v, atol=2e-6, rtol=0)
+    want_p2p, _ = metrics_np.p2p_error(reg, reg, gts, fits)
+    np.testing.assert_allclose(res['p2p'], want_p2p, atol=1e-9, rtol=0)
+    lm = om.load_landmarks(osp.join(data, 'measurement_defitions.yaml'),
+                           osp.join(data, 'smplx_measurements.yaml'))
+    mg, mf = om.body_measurements(gts[:, faces], lm), om.body_measurements(fits[:, faces], lm)
+    for k in ('height', 'chest', 'waist', 'hips', 'mass'):
+        np.testing.assert_allclose(res[k], np.abs(mg[k].astype(np.float64) - mf[k]),
+                                   atol=2e-4 if k == 'mass' else 3e-6, rtol=0, err_msg=k)
