@@ -64,7 +64,7 @@ def conv_flop_per_image(net, size):
     return 2 * macs
 
 
-def pmc_traffic(batch, size, dtype='f32'):
+def pmc_traffic(batch, size, dtype='f32', algo='direct'):
     """HBM bytes per backbone forward from the committed rocprofv3 --pmc passes
     (profiles/*_pmc_hbm_traffic*.json; FETCH_SIZE and WRITE_SIZE need separate passes and cannot
     be collected from inside this process).  None when the workload differs."""
@@ -73,7 +73,8 @@ def pmc_traffic(batch, size, dtype='f32'):
         with open(f) as fh:
             d = json.load(fh)
         h = d.get('hbm_bytes_per_backbone_forward', {})
-        if h.get('batch') == batch and h.get('size') == size and h.get('dtype', 'f32') == dtype:
+        if (h.get('batch') == batch and h.get('size') == size and h.get('dtype', 'f32') == dtype
+                and h.get('algo', 'direct') == (algo if dtype == 'f32' else h.get('algo', 'direct'))):
             return {'bytes_as_reported': h['as_reported'], 'bytes_fetch_x2_corrected':
                     h['fetch_x2_corrected'], 'source': osp.relpath(f, ROOT)}
     return None
@@ -381,7 +382,7 @@ def run_regressor(args, rank, world, local_rank):
                   f'algo={algo}; achieved counts the ALGORITHMIC direct-conv FLOPs)'
     # HBM bytes per launch group (one backbone forward) from the committed PMC passes, gfx950
     # FETCH x2 correction applied
-    traffic = pmc_traffic(B, args.size, args.dtype)
+    traffic = pmc_traffic(B, args.size, args.dtype, algo)
     if rank != 0:
         return None
     res = {

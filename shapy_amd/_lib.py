@@ -63,6 +63,8 @@ for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: con
     TILES[_k + '+bk16'] = _v | 0x800
     TILES[_k + '+noswz+bk16'] = _v | 0xC00
     TILES[_k + '+direct'] = _v | 0x2000       # never take the Winograd path
+    TILES[_k + '+wtm1'] = _v | 0x4000         # Winograd: 16 tiles per workgroup
+    TILES[_k + '+wtm2'] = _v | 0x8000         # Winograd: 32 tiles per workgroup
 
 #: every symbol include/shapy_hip.h declares: (restype, argtypes)
 SIGNATURES = {

@@ -46,7 +46,7 @@ struct ConvK {
 
 // Winograd F(2x2,3x3) path of the float32 3x3 / stride-1 layers (conv_wino.hip)
 bool conv_wino_eligible(const ConvK &k);
-int conv2d_wino(ConvK k, hipStream_t s);
+int conv2d_wino(ConvK k, int tm, hipStream_t s);
 
 // float32 storage, bf16x6 split arithmetic on the bf16 matrix cores (conv_x6.hip)
 int conv2d_x6(const ConvK &k, int tile, hipStream_t s);

@@ -280,10 +280,11 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   k.in_bytes = (unsigned)in_bytes; k.wgt_bytes = (unsigned)wgt_bytes;
   if (k.M <= 0 || k.Cout <= 0) return SHAPY_OK;
   // Winograd F(2x2,3x3) when the caller supplies the transformed filters (the host's policy,
-  // HighResolutionNet.conv_algo); tile flag 0x2000 forces the direct kernel (A/B benches)
+  // HighResolutionNet.conv_algo); tile flag 0x2000 forces the direct kernel, 0x4000 / 0x8000
+  // one / two tile groups per Winograd workgroup (A/B benches)
   k.wgt2 = d.wgt_wino; k.wgt2_bytes = 0; k.wino_tiles = 0;
   if (d.dtype == SHAPY_DTYPE_F32 && !(d.tile & 0x2000) && conv_wino_eligible(k))
-    return conv2d_wino(k, s);
+    return conv2d_wino(k, (d.tile & 0x4000) ? 1 : (d.tile & 0x8000) ? 2 : 0, s);
   // d.tile: low byte = SHAPY_TILE_* (0 = auto).  Tuning knobs of tools/conv_bench.py:
   // 0x400 disables the XCD-contiguous workgroup order, 0x200 / 0x800 force the long (8 slots =
   // 128-byte rows) / short (4 slots) K chunk.  Defaults (profiles/conv_bench_r01*.txt):

@@ -23,6 +23,9 @@
 //     straight from the transformed filters in global memory (L2-resident, layout
 //     [p][Cin/16][Cout][16]: 1 KB contiguous per wave load; they are not shared between waves,
 //     so LDS would only add a round trip), prefetched one chunk ahead;
+//   * two V buffers, one barrier per chunk (their memory is needed for the epilogue anyway);
+//     TM = 2 tile groups per workgroup reuse every B fragment twice (half the L2 traffic of the
+//     transformed filters, the dominant stream: 147 KB per workgroup for a 48 -> 48 layer);
 //   * epilogue: the 16 positions of a (tile, channel) sit in 4 different waves: accumulators
 //     are parked in LDS (aliasing the staging buffer), then thread (tile, 4 channels) applies
 //     A^T . A, bias, residual, ReLU and stores 4 pixels x 16 bytes (whole 192-byte rows per
@@ -36,16 +39,19 @@ __device__ __forceinline__ float quad_partner(float x) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x5A, 0xf, 0xf, true));
 }
 
-template <int NN>
-__global__ __launch_bounds__(256, 3) void conv_wino_kernel(ConvK p) {
-  constexpr int N = 16 * NN, NCP = N + 4, N4 = N / 4;
-  constexpr int LDS_V = 16 * 16 * 64;                 // V[16 pos][16 tiles][16 ch] f32
+template <int NN, int TM>
+__global__ __launch_bounds__(256, (TM == 1 ? 3 : 2)) void conv_wino_kernel(ConvK p) {
+  constexpr int N = 16 * NN, NCP = N + 4, N4 = N / 4, MT = 16 * TM;
+  constexpr int PSTR = MT * 64;                       // bytes per position in a V buffer
+  constexpr int LDS_V = 16 * PSTR;                    // V[16 pos][MT tiles][16 ch] f32
   constexpr int LDS_X = 16 * 16 * NCP * 4;            // M[16 pos][16 tiles][N + 4] f32
-  __shared__ __attribute__((aligned(16))) char lds[LDS_X > LDS_V ? LDS_X : LDS_V];
+  // two V buffers (one barrier per chunk: chunk c+1 is staged while chunk c is multiplied); the
+  // accumulator exchange of the epilogue reuses the same memory
+  __shared__ __attribute__((aligned(16))) char lds[2 * LDS_V > LDS_X ? 2 * LDS_V : LDS_X];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wg = conv_tile_index(p);
-  const int m_blk = (wg / p.nbx) * 16, n_blk = (wg % p.nbx) * N;
+  const int m_blk = (wg / p.nbx) * MT, n_blk = (wg % p.nbx) * N;
   const int H = p.Hi, W = p.Wi;
   const int TW = (W + 1) >> 1, TH = (H + 1) >> 1;
   const int T = p.wino_tiles;
@@ -56,55 +62,61 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(ConvK p) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt2), 0, p.wgt2_bytes, 0x00020000);
   constexpr int OOB = 0x7fffffff;
 
-  // ---- staging role: (patch row r, tile, 4-channel group c4) ----
+  // ---- staging role: (patch row r, tile, 4-channel group c4), TM tiles per thread ----
   const int r = t & 3, c4 = (t >> 3) & 3, tile_s = ((t >> 5) << 1) | ((t >> 2) & 1);
-  int a_off;
-  bool xok[4], rowok;
-  {
-    const int tile = m_blk + tile_s;
+  int a_off[TM];
+  bool xok[TM][4], rowok[TM];
+#pragma unroll
+  for (int s = 0; s < TM; ++s) {
+    const int tile = m_blk + 16 * s + tile_s;
     const int tt = tile < T ? tile : 0;
     const int tx = tt % TW;
     const int tq = tt / TW;
     const int ty = tq % TH;
     const int b = tq / TH;
     const int y = 2 * ty - 1 + r, x0 = 2 * tx - 1;
-    rowok = tile < T && (unsigned)y < (unsigned)H;
-    a_off = (((b * H + y) * W + x0) * p.in_ld + c4 * 4) * 4;
+    rowok[s] = tile < T && (unsigned)y < (unsigned)H;
+    a_off[s] = (((b * H + y) * W + x0) * p.in_ld + c4 * 4) * 4;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) xok[k] = (unsigned)(x0 + k) < (unsigned)W;
+    for (int k = 0; k < 4; ++k) xok[s][k] = (unsigned)(x0 + k) < (unsigned)W;
   }
   const int pix_stride = p.in_ld * 4;
   const float so = r == 3 ? -1.f : 1.f, sp = (r == 1 || r == 3) ? 1.f : -1.f;
   const int fsw = (tile_s ^ (tile_s >> 1)) & 3;
-  const int st_off = tile_s * 64 + (((c4 ^ fsw ^ r) & 3) << 4) + 4 * r * 1024;   // + j * 1024
+  const int st_off = tile_s * 64 + (((c4 ^ fsw ^ r) & 3) << 4) + 4 * r * PSTR;   // + j * PSTR
 
-  u32x4 raw[4];
+  u32x4 raw[TM][4];
   // loads past the last chunk are issued with an out-of-range offset (they return 0 without
   // touching memory): no branch around them, so the compiler's vmcnt counts stay exact
   auto gload = [&](int c0, bool live) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      raw[k] = __builtin_amdgcn_raw_buffer_load_b128(
-          rs_in, (live && rowok && xok[k]) ? a_off + k * pix_stride + c0 * 4 : OOB, 0, 0);
+    for (int s = 0; s < TM; ++s)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        raw[s][k] = __builtin_amdgcn_raw_buffer_load_b128(
+            rs_in, (live && rowok[s] && xok[s][k]) ? a_off[s] + k * pix_stride + c0 * 4 : OOB, 0, 0);
   };
-  auto lstore = [&]() {
-    f32x4 d[4], tr[4];
+  auto lstore = [&](int buf) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) d[k] = __builtin_bit_cast(f32x4, raw[k]);
-    tr[0] = d[0] - d[2];                  // T = d B   (columns of the patch row)
-    tr[1] = d[1] + d[2];
-    tr[2] = d[2] - d[1];
-    tr[3] = d[1] - d[3];
+    for (int s = 0; s < TM; ++s) {
+      f32x4 d[4], tr[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 v;
+      for (int k = 0; k < 4; ++k) d[k] = __builtin_bit_cast(f32x4, raw[s][k]);
+      tr[0] = d[0] - d[2];                  // T = d B   (columns of the patch row)
+      tr[1] = d[1] + d[2];
+      tr[2] = d[2] - d[1];
+      tr[3] = d[1] - d[3];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaf(sp, quad_partner(tr[j][e]), so * tr[j][e]);   // B^T T
-      *reinterpret_cast<f32x4 *>(lds + st_off + j * 1024) = v;
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(sp, quad_partner(tr[j][e]), so * tr[j][e]);   // B^T T
+        *reinterpret_cast<f32x4 *>(lds + buf * LDS_V + st_off + s * 1024 + j * PSTR) = v;
+      }
     }
   };
 
-  // ---- MFMA role: wave w owns positions 4 w + pp, all NN channel tiles ----
+  // ---- MFMA role: wave w owns positions 4 w + pp, all TM tile groups x NN channel tiles ----
   const int kq = lane >> 4, l15 = lane & 15;
   const int frag_off = l15 * 64 + (((kq ^ ((l15 ^ (l15 >> 1)) & 3) ^ wave) & 3) << 4);
   const int CC = p.Cin >> 4;
@@ -120,113 +132,126 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(ConvK p) {
       bfr[pp][n] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, base + n * 1024, 0, 0);
   };
 
-  f32x4 acc[4][NN];
+  f32x4 acc[4][TM][NN];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int n = 0; n < NN; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int n = 0; n < NN; ++n) acc[i][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   gload(0, true);
 #pragma unroll
   for (int pp = 0; pp < 4; ++pp) bload(pp, 0, true);
-  lstore();
+  lstore(0);
   __syncthreads();
 
   for (int cc = 0; cc < CC; ++cc) {
     const bool more = cc + 1 < CC;
+    const char *Vb = lds + (cc & 1) * LDS_V;
     gload((cc + 1) * 16, more);
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
-      const u32x4 af =
-          *reinterpret_cast<const u32x4 *>(lds + (4 * wave + pp) * 1024 + frag_off);
+      u32x4 af[TM];
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+        af[m] = *reinterpret_cast<const u32x4 *>(Vb + (4 * wave + pp) * PSTR + m * 1024 + frag_off);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int n = 0; n < NN; ++n)
-          acc[pp][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-              __uint_as_float(af[kk]), __uint_as_float(bfr[pp][n][kk]), acc[pp][n], 0, 0, 0);
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < NN; ++n)
+            acc[pp][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                __uint_as_float(af[m][kk]), __uint_as_float(bfr[pp][n][kk]), acc[pp][m][n], 0, 0, 0);
       bload(pp, cc + 1, more);
     }
-    __syncthreads();                         // everybody is done reading V
-    lstore();                                // (zeros after the last chunk: never read)
+    // the other buffer was last read in iteration cc - 1, which every wave left through the
+    // barrier below: it can be overwritten while slower waves still multiply this one
+    lstore((cc + 1) & 1);                    // (zeros after the last chunk: never read)
     __syncthreads();
   }
 
-  // ---- park the accumulators: M[p][tile][channel] ----
-  {
-    float *M = reinterpret_cast<float *>(lds);
-#pragma unroll
-    for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-      for (int n = 0; n < NN; ++n)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          M[((4 * wave + pp) * 16 + 4 * kq + rg) * NCP + n * 16 + l15] = acc[pp][n][rg];
-  }
-  __syncthreads();
-
-  // ---- output transform + epilogue: thread (tile, 4 channels) ----
   const float *res = reinterpret_cast<const float *>(p.res);
   float *out = reinterpret_cast<float *>(p.out);
-  for (int it = t; it < 16 * N4; it += 256) {
-    const int c4o = it % N4, tl = it / N4;
-    const int tile = m_blk + tl;
-    if (tile >= T) continue;
-    const int col = n_blk + c4o * 4;
-    if (col >= p.Cout) continue;
-    const int tx = tile % TW;
-    const int tq = tile / TW;
-    const int ty = tq % TH;
-    const int b = tq / TH;
-    const float *Mp = reinterpret_cast<const float *>(lds) + tl * NCP + c4o * 4;
-    f32x4 tt[4][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 m0 = *reinterpret_cast<const f32x4 *>(Mp + (i * 4 + 0) * 16 * NCP);
-      const f32x4 m1 = *reinterpret_cast<const f32x4 *>(Mp + (i * 4 + 1) * 16 * NCP);
-      const f32x4 m2 = *reinterpret_cast<const f32x4 *>(Mp + (i * 4 + 2) * 16 * NCP);
-      const f32x4 m3 = *reinterpret_cast<const f32x4 *>(Mp + (i * 4 + 3) * 16 * NCP);
-      tt[i][0] = (m0 + m1) + m2;             // M A
-      tt[i][1] = (m1 - m2) - m3;
+  for (int mt = 0; mt < TM; ++mt) {
+    // ---- park the accumulators of tile group mt: M[p][tile][channel] ----
+    if (mt > 0) __syncthreads();             // the previous group's M has been consumed
+    {
+      float *M = reinterpret_cast<float *>(lds);
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            M[((4 * wave + pp) * 16 + 4 * kq + rg) * NCP + n * 16 + l15] = acc[pp][mt][n][rg];
     }
-    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias = *reinterpret_cast<const f32x4 *>(p.bias + col);
-    f32x4 y[2][2];
+    __syncthreads();
+
+    // ---- output transform + epilogue: thread (tile, 4 channels) ----
+    for (int it = t; it < 16 * N4; it += 256) {
+      const int c4o = it % N4, tl = it / N4;
+      const int tile = m_blk + 16 * mt + tl;
+      if (tile >= T) continue;
+      const int col = n_blk + c4o * 4;
+      if (col >= p.Cout) continue;
+      const int tx = tile % TW;
+      const int tq = tile / TW;
+      const int ty = tq % TH;
+      const int b = tq / TH;
+      const float *Mp = reinterpret_cast<const float *>(lds) + tl * NCP + c4o * 4;
+      f32x4 tt[4][2];
 #pragma unroll
-    for (int bb = 0; bb < 2; ++bb) {
-      y[0][bb] = ((tt[0][bb] + tt[1][bb]) + tt[2][bb]) + bias;      // A^T (M A)
-      y[1][bb] = ((tt[1][bb] - tt[2][bb]) - tt[3][bb]) + bias;
-    }
-    const int oy = 2 * ty, ox = 2 * tx;
-    bool ok[2][2];
-    long pix[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 m0 = *reinterpret_cast<const f32x4 *>(Mp + (i * 4 + 0) * 16 * NCP);
+        const f32x4 m1 = *reinterpret_cast<const f32x4 *>(Mp + (i * 4 + 1) * 16 * NCP);
+        const f32x4 m2 = *reinterpret_cast<const f32x4 *>(Mp + (i * 4 + 2) * 16 * NCP);
+        const f32x4 m3 = *reinterpret_cast<const f32x4 *>(Mp + (i * 4 + 3) * 16 * NCP);
+        tt[i][0] = (m0 + m1) + m2;             // M A
+        tt[i][1] = (m1 - m2) - m3;
+      }
+      f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bias = *reinterpret_cast<const f32x4 *>(p.bias + col);
+      f32x4 y[2][2];
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb) {
-        ok[a][bb] = oy + a < H && ox + bb < W;
-        pix[a][bb] = ((long)(b * H + oy + a) * W + ox + bb);
+        y[0][bb] = ((tt[0][bb] + tt[1][bb]) + tt[2][bb]) + bias;      // A^T (M A)
+        y[1][bb] = ((tt[1][bb] - tt[2][bb]) - tt[3][bb]) + bias;
       }
-    if (res) {
+      const int oy = 2 * ty, ox = 2 * tx;
+      bool ok[2][2];
+      long pix[2][2];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
-          if (ok[a][bb])
-            y[a][bb] += *reinterpret_cast<const f32x4 *>(res + pix[a][bb] * p.res_ld + p.res_coff + col);
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        if (!ok[a][bb]) continue;
-        f32x4 v = y[a][bb];
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int bb = 0; bb < 2; ++bb) {
+          ok[a][bb] = oy + a < H && ox + bb < W;
+          pix[a][bb] = ((long)(b * H + oy + a) * W + ox + bb);
         }
-        *reinterpret_cast<f32x4 *>(out + pix[a][bb] * p.out_ld + p.out_coff + col) = v;
+      if (res) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb)
+            if (ok[a][bb])
+              y[a][bb] +=
+                  *reinterpret_cast<const f32x4 *>(res + pix[a][bb] * p.res_ld + p.res_coff + col);
       }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          if (!ok[a][bb]) continue;
+          f32x4 v = y[a][bb];
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          *reinterpret_cast<f32x4 *>(out + pix[a][bb] * p.out_ld + p.out_coff + col) = v;
+        }
+    }
   }
 }
 
@@ -236,15 +261,22 @@ bool conv_wino_eligible(const ConvK &k) {
          (!k.bias || ((uintptr_t)k.bias & 15) == 0);
 }
 
-int conv2d_wino(ConvK k, hipStream_t s) {
+// tm: 0 = choose, 1 / 2 = tile groups (16 tiles each) per workgroup.  Two groups halve the
+// filter traffic per MFMA (the B fragments are reused for both) at 2 instead of 3 workgroups
+// per CU; layers with few tiles keep 1 so that the grid still fills the chip.
+int conv2d_wino(ConvK k, int tm, hipStream_t s) {
   const int B = k.M / (k.Ho * k.Wo);
   k.wino_tiles = B * ((k.Hi + 1) / 2) * ((k.Wi + 1) / 2);
   const unsigned long long wb = 64ull * k.Cin * k.Cout;        // 16 positions x f32
   if (wb >= 0x7fffffffull) return SHAPY_EINVAL;
   k.wgt2_bytes = (unsigned)wb;
   k.nbx = k.Cout / 48;
-  k.nby = (k.wino_tiles + 15) / 16;
-  hipLaunchKernelGGL((conv_wino_kernel<3>), dim3(k.nbx * k.nby), dim3(256), 0, s, k);
+  if (tm == 0) tm = (long)((k.wino_tiles + 31) / 32) * k.nbx >= 1024 ? 2 : 1;
+  k.nby = (k.wino_tiles + 16 * tm - 1) / (16 * tm);
+  if (tm == 2)
+    hipLaunchKernelGGL((conv_wino_kernel<3, 2>), dim3(k.nbx * k.nby), dim3(256), 0, s, k);
+  else
+    hipLaunchKernelGGL((conv_wino_kernel<3, 1>), dim3(k.nbx * k.nby), dim3(256), 0, s, k);
   return (int)hipGetLastError();
 }
 

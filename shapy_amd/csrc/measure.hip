@@ -107,6 +107,37 @@ __device__ __forceinline__ float lm_coord(VF vtx, const int32_t *faces, const La
   return (a * lm.bc[which][0] + b * lm.bc[which][1]) + c * lm.bc[which][2];
 }
 
+// SAT + first-hit point of one (face, plane, plane triangle) candidate of the fused scan
+__device__ __forceinline__ void measure_candidate(const Tri &t, float h, int f, long list, int qi,
+                                                  int CAP, int *__restrict__ counters,
+                                                  float4 *__restrict__ points) {
+  // _get_plane_at_heights (body_measurements.py:86-97): quad (c0,c1,c2,c3) as 2 triangles
+  Tri q;
+  q.v0 = v3(-1.f, h, -1.f);
+  q.v1 = qi == 0 ? v3(1.f, h, -1.f) : v3(1.f, h, 1.f);
+  q.v2 = qi == 0 ? v3(1.f, h, 1.f) : v3(-1.f, h, 1.f);
+  if (!(aabb_overlap(q, t) && tri_tri_sat(q, t))) return;
+  const int slot = atomicAdd(counters + list, 1);
+  if (slot >= CAP) return;
+  V3 bc = v3(0.f, 0.f, 0.f);
+  tri_tri_point(q, t, bc);
+  // points = sum_k bc_k * tri_k (body_measurements.py:144-147)
+  float4 pt;
+  pt.x = (t.v0.x * bc.x + t.v1.x * bc.y) + t.v2.x * bc.z;
+  pt.y = (t.v0.y * bc.x + t.v1.y * bc.y) + t.v2.y * bc.z;
+  pt.z = (t.v0.z * bc.x + t.v1.z * bc.y) + t.v2.z * bc.z;
+  pt.w = __int_as_float(f);
+  points[list * CAP + slot] = pt;
+}
+
+// out-of-line copy for the queue-overflow path of the scan loop (never taken for a body): keeps
+// the SAT code's registers out of the streaming loop
+__device__ __noinline__ void measure_candidate_noinline(const Tri &t, float h, int f, long list,
+                                                        int qi, int CAP, int *counters,
+                                                        float4 *points) {
+  measure_candidate(t, h, f, list, qi, CAP, counters, points);
+}
+
 constexpr int M2_THREADS = 1024;            // 16 waves: one workgroup owns a CU's LDS
 constexpr int M2_QCAP = 4096;               // candidate queue entries (face * 4 + plane)
 constexpr int M2_MAX_SLICES = 16;
@@ -121,7 +152,7 @@ constexpr int M2_LDS_TOTAL = 160 * 1024;
 // -- AABB + 11-axis SAT + first-hit point for both plane triangles -- runs afterwards on the
 // dense queue (in the scan it would run with 1-2 active lanes in 3 of 4 wave iterations).
 // Hit slots come from one global atomic per hit (~300 per mesh); the hull kernel sorts, so the
-// order does not matter.  !STAGED (triangle soups of the reference signature, V = 3 F): same
+// order does not matter.  No barrier inside the scan loop.  !STAGED (triangle soups of the reference signature, V = 3 F): same
 // code, coordinates gathered from global memory, the faces of a mesh split over several slices.
 template <bool STAGED>
 __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
@@ -147,7 +178,22 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
     const int n4 = (N - head) >> 2;
     const float4 *g4 = reinterpret_cast<const float4 *>(vb + head);
     float4 *s4 = reinterpret_cast<float4 *>(sv + shift + head);
-    for (int i = tid; i < n4; i += M2_THREADS) s4[i] = g4[i];
+    // all loads of a thread in flight before the first LDS store (8 x 16 bytes per thread for
+    // SMPL-X): the copy runs at the HBM rate instead of one round trip per iteration
+    constexpr int LD = 8;
+    for (int i0 = tid; i0 < n4; i0 += LD * M2_THREADS) {
+      float4 tmp[LD];
+#pragma unroll
+      for (int u = 0; u < LD; ++u) {
+        const int i = i0 + u * M2_THREADS;
+        tmp[u] = i < n4 ? g4[i] : float4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < LD; ++u) {
+        const int i = i0 + u * M2_THREADS;
+        if (i < n4) s4[i] = tmp[u];
+      }
+    }
     for (int i = head + n4 * 4 + tid; i < N; i += M2_THREADS) sv[shift + i] = vb[i];
   }
   if (tid == 0) qn = 0;
@@ -166,63 +212,58 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
     t.v2 = v3(vtx(i2, 0), vtx(i2, 1), vtx(i2, 2));
     return t;
   };
-  auto drain = [&]() {
-    const int n = qn < M2_QCAP ? qn : M2_QCAP;
-    for (int p = tid; p < 2 * n; p += M2_THREADS) {
-      const int c = queue[p >> 1], qi = p & 1, f = c >> 2, pl = c & 3;
-      const Tri t = load_face(f);
-      const float h = hs[pl];
-      // _get_plane_at_heights (body_measurements.py:86-97): quad (c0,c1,c2,c3) as 2 triangles
-      Tri q;
-      q.v0 = v3(-1.f, h, -1.f);
-      q.v1 = qi == 0 ? v3(1.f, h, -1.f) : v3(1.f, h, 1.f);
-      q.v2 = qi == 0 ? v3(1.f, h, 1.f) : v3(-1.f, h, 1.f);
-      if (!(aabb_overlap(q, t) && tri_tri_sat(q, t))) continue;
-      const long list = ((long)b * 3 + pl) * 2 + qi;
-      const int slot = atomicAdd(counters + list, 1);
-      if (slot >= CAP) continue;
-      V3 bc = v3(0.f, 0.f, 0.f);
-      tri_tri_point(q, t, bc);
-      // points = sum_k bc_k * tri_k (body_measurements.py:144-147)
-      float4 pt;
-      pt.x = (t.v0.x * bc.x + t.v1.x * bc.y) + t.v2.x * bc.z;
-      pt.y = (t.v0.y * bc.x + t.v1.y * bc.y) + t.v2.y * bc.z;
-      pt.z = (t.v0.z * bc.x + t.v1.z * bc.y) + t.v2.z * bc.z;
-      pt.w = __int_as_float(f);
-      points[list * CAP + slot] = pt;
-    }
+  auto process = [&](int f, int pl, int qi, const Tri &t) {
+    measure_candidate(t, hs[pl], f, ((long)b * 3 + pl) * 2 + qi, qi, CAP, counters, points);
+  };
+  auto process_slow = [&](int f, int pl, int qi, const Tri &t) {
+    measure_candidate_noinline(t, hs[pl], f, ((long)b * 3 + pl) * 2 + qi, qi, CAP, counters, points);
   };
 
+  // The scan runs without barriers (every wave streams its faces at its own pace; the face
+  // indices of the next iteration are in flight while this one is evaluated).  A candidate that
+  // does not fit into the queue any more (> 4096 per mesh slice: not a body) is evaluated on
+  // the spot by the thread that found it.
   const int f_lo = blockIdx.x * Fs, f_hi = min(F, f_lo + Fs);
   double vol = 0.0;
-  for (int f0 = f_lo; f0 < f_hi; f0 += M2_THREADS) {
-    const int f = f0 + tid;
-    if (f < f_hi) {
-      const Tri t = load_face(f);
-      // compute_mass (body_measurements.py:201-215), term order as written there
-      const float x0 = t.v0.x, y0 = t.v0.y, z0 = t.v0.z, x1 = t.v1.x, y1 = t.v1.y, z1 = t.v1.z,
-                  x2 = t.v2.x, y2 = t.v2.y, z2 = t.v2.z;
-      const float vv = -x2 * y1 * z0 + x1 * y2 * z0 + x2 * y0 * z1 - x0 * y2 * z1 - x1 * y0 * z2 +
-                       x0 * y1 * z2;
-      vol += (double)vv;
-      const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
+  int f = f_lo + tid;
+  int i0 = 0, i1 = 0, i2 = 0;
+  if (f < f_hi) { i0 = faces[f * 3]; i1 = faces[f * 3 + 1]; i2 = faces[f * 3 + 2]; }
+  while (f < f_hi) {
+    const int fn = f + M2_THREADS;
+    int n0 = 0, n1 = 0, n2 = 0;
+    if (fn < f_hi) { n0 = faces[fn * 3]; n1 = faces[fn * 3 + 1]; n2 = faces[fn * 3 + 2]; }
+    Tri t;
+    t.v0 = v3(vtx(i0, 0), vtx(i0, 1), vtx(i0, 2));
+    t.v1 = v3(vtx(i1, 0), vtx(i1, 1), vtx(i1, 2));
+    t.v2 = v3(vtx(i2, 0), vtx(i2, 1), vtx(i2, 2));
+    // compute_mass (body_measurements.py:201-215), term order as written there
+    const float x0 = t.v0.x, y0 = t.v0.y, z0 = t.v0.z, x1 = t.v1.x, y1 = t.v1.y, z1 = t.v1.z,
+                x2 = t.v2.x, y2 = t.v2.y, z2 = t.v2.z;
+    const float vv = -x2 * y1 * z0 + x1 * y2 * z0 + x2 * y0 * z1 - x0 * y2 * z1 - x1 * y0 * z2 +
+                     x0 * y1 * z2;
+    vol += (double)vv;
+    const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        if (ymin <= hs[pl] && ymax >= hs[pl]) {      // the y part of the AABB test
-          const int slot = atomicAdd(&qn, 1);
-          if (slot < M2_QCAP) queue[slot] = f * 4 + pl;
+    for (int pl = 0; pl < 3; ++pl)
+      if (ymin <= hs[pl] && ymax >= hs[pl]) {        // the y part of the AABB test
+        const int slot = atomicAdd(&qn, 1);
+        if (slot < M2_QCAP) {
+          queue[slot] = f * 4 + pl;
+        } else {
+          process_slow(f, pl, 0, t);
+          process_slow(f, pl, 1, t);
         }
-    }
-    __syncthreads();
-    // a chunk adds at most 3 entries per thread: drain before the queue could overflow
-    if (qn > M2_QCAP - 3 * M2_THREADS) {
-      drain();
-      __syncthreads();
-      if (tid == 0) qn = 0;
-      __syncthreads();
+      }
+    f = fn; i0 = n0; i1 = n1; i2 = n2;
+  }
+  __syncthreads();
+  {
+    const int n = qn < M2_QCAP ? qn : M2_QCAP;
+    for (int p = tid; p < 2 * n; p += M2_THREADS) {
+      const int c = queue[p >> 1];
+      process(c >> 2, c & 3, p & 1, load_face(c >> 2));
     }
   }
-  drain();
   // deterministic reduction of the signed volume (fixed lane / wave order)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) vol += __shfl_xor(vol, o, 64);

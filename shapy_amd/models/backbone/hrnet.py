@@ -343,12 +343,13 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: exact 3-way bf16 split on the bf16 matrix cores (float32-class accuracy);
         #: 'bf16' = bf16 weights/activations, f32 accumulate
         self.compute_dtype = 'f32'
-        #: float32 convolution algorithm of the 3x3 / stride-1 layers: 'direct' = implicit GEMM
-        #: for every layer (the exact-f32 fmaf chain); 'winograd' = Winograd F(2x2,3x3)
-        #: (csrc/conv_wino.hip, 2.25x fewer MFMAs, float32-class result) wherever the kernel
-        #: applies; 'auto' = Winograd on feature maps of at least wino_min_hw pixels a side
-        #: (small maps have too few tiles to fill the chip and pad 7 -> 8)
-        self.conv_algo = 'direct'
+        #: float32 convolution algorithm of the 3x3 / stride-1 layers: 'winograd' (default) =
+        #: Winograd F(2x2,3x3) (csrc/conv_wino.hip, 2.25x fewer MFMAs, float32-class result:
+        #: same 1e-4 parity tests) wherever the kernel applies -- measured faster on every
+        #: eligible HRNet class incl. the 7x7 maps (profiles/conv_bench_r02*); 'direct' =
+        #: implicit GEMM for every layer (the exact-f32 fmaf chain of the reference's sum
+        #: order); 'auto' = Winograd only on maps of at least wino_min_hw pixels a side
+        self.conv_algo = 'winograd'
         self.wino_min_hw = 14
         self._engine_ver = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())

@@ -137,8 +137,9 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize('tm', [1, 2])
 @pytest.mark.parametrize('case', WINO_CASES, ids=[str(c) for c in WINO_CASES])
-def test_conv_winograd_kernel_vs_float64(lib, case):
+def test_conv_winograd_kernel_vs_float64(lib, case, tm):
     """csrc/conv_wino.hip through shapy_conv2d (ShapyConv.wgt_wino) against float64, and
     against the direct kernel on the same operands."""
     B, H, W, Cin, Cout, use_res, relu = case
@@ -147,7 +148,7 @@ def test_conv_winograd_kernel_vs_float64(lib, case):
     w = (torch.randn(Cout, 3, 3, Cin, generator=g) / np.sqrt(9 * Cin)).cuda()
     b = torch.randn(Cout, generator=g).cuda()
     res = torch.randn(B, H, W, Cout, generator=g).cuda() if use_res else None
-    out = _conv_call(lib, x, w, b, res, relu, 1, 1, wino=True)
+    out = _conv_call(lib, x, w, b, res, relu, 1, 1, tile=0x4000 * tm, wino=True)   # 16 tm tiles / WG
     direct = _conv_call(lib, x, w, b, res, relu, 1, 1, tile=0x2000, wino=True)   # forced direct
     ref = _conv_ref(x, w, b, res, relu, 1, 1)
     e = (out.cpu().double() - ref).abs()
@@ -302,7 +303,9 @@ def network():
     net = build_model(cfg)['network']
     syn.fill_module_synthetic(net, 0)
     net = net.to('cuda').eval()
-    return net
+    assert net.backbone.conv_algo == 'winograd'        # the product default (smoke / bench use it)
+    net.backbone.conv_algo = 'direct'                  # baseline of this module: the exact-f32
+    return net                                         # direct path; Winograd tests opt in
 
 
 @pytest.mark.parametrize('tag,b,s', [('b2_64', 2, 64), ('b3_96', 3, 96), ('b1_224', 1, 224)])
