@@ -83,10 +83,13 @@ SIGNATURES = {
     'shapy_regressor_affine_f32': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, vp]),
+    'shapy_regressor_collapsed_f32': (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_int, ctypes.c_int, vp]),
     'shapy_joint_regress_f32': (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, vp]),
     'shapy_smplx_pose_f32': (ctypes.c_int, [ctypes.POINTER(ShapySmplxModel), vp, ctypes.c_int,
                                             ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_int, vp]),
+    'shapy_head_prepare_f32': (ctypes.c_int, [vp] + [ctypes.c_int] * 10 + [vp, vp, vp, vp]),
     'shapy_pose_decode_f32': (ctypes.c_int, [vp, ctypes.c_int, vp, i64, vp]),
     'shapy_weak_persp_project_f32': (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int,
                                                     ctypes.c_int, vp]),

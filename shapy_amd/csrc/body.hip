@@ -15,9 +15,12 @@ namespace shapy {
 // every body and ran on 64 of 256 CUs: 196 us at B = 64).  Per (row, body) the summation order
 // is unchanged: lane l accumulates k = 4 l + 256 i in order, then a butterfly over the wave.
 constexpr int REG_RB = 8;
+// PS > 0: the rows are S stacked stages of PS parameters each (fully collapsed regressor,
+// shapy_regressor_collapsed_f32) and row r = s * PS + i of body b is written to
+// t_out[(s * B + b) * PS + i], the [S,B,P] layout of params_out.
 __global__ __launch_bounds__(256) void regressor_feat_kernel(
     const float *__restrict__ feat, const float *__restrict__ Wf, const float *__restrict__ bias,
-    float *__restrict__ t_out, int B, int F, int P) {
+    float *__restrict__ t_out, int B, int F, int P, int PS) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wave, b0 = blockIdx.y * REG_RB;
   if (r >= P) return;
@@ -38,7 +41,10 @@ __global__ __launch_bounds__(256) void regressor_feat_kernel(
 #pragma unroll
   for (int j = 0; j < REG_RB; ++j) {
     const float v = wave_reduce_sum(s[j]);
-    if (lane == 0 && b0 + j < B) t_out[(long)(b0 + j) * P + r] = v + bias[r];
+    if (lane == 0 && b0 + j < B) {
+      if (PS > 0) t_out[((long)(r / PS) * B + b0 + j) * PS + r % PS] = v + bias[r];
+      else t_out[(long)(b0 + j) * P + r] = v + bias[r];
+    }
   }
 }
 
@@ -307,13 +313,10 @@ __global__ __launch_bounds__(128) void smplx_joints_kernel(JointsK k) {
 // ------------------------------------------------------------------------------------------
 // stand-alone pose decoders (pose_utils.py:138-153 / rotation_utils.py:5-37) and camera
 // ------------------------------------------------------------------------------------------
-__global__ void pose_decode_kernel(const float *__restrict__ x, int type, float *__restrict__ out,
-                                   long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float r[9];
+// one rotation from its parameters: 6-D continuous representation (pose_utils.py:138-153,
+// x viewed as (3,2): interleaved [a1x,a2x,a1y,a2y,a1z,a2z]) or axis-angle (rotation_utils.py:5-37)
+__device__ __forceinline__ void decode_rotation(const float *p, int type, float (&r)[9]) {
   if (type == SHAPY_POSE_CONT6D) {
-    const float *p = x + i * 6;
     const float a1x = p[0], a2x = p[1], a1y = p[2], a2y = p[3], a1z = p[4], a2z = p[5];
     const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
     const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
@@ -325,7 +328,6 @@ __global__ void pose_decode_kernel(const float *__restrict__ x, int type, float 
     r[3] = b1y; r[4] = b2y; r[5] = b1z * b2x - b1x * b2z;
     r[6] = b1z; r[7] = b2z; r[8] = b1x * b2y - b1y * b2x;
   } else {
-    const float *p = x + i * 3;
     const float ex = p[0] + 1e-8f, ey = p[1] + 1e-8f, ez = p[2] + 1e-8f;
     const float ang = sqrtf(ex * ex + ey * ey + ez * ez);
     const float rx = p[0] / ang, ry = p[1] / ang, rz = p[2] / ang;
@@ -336,8 +338,48 @@ __global__ void pose_decode_kernel(const float *__restrict__ x, int type, float 
 #pragma unroll
     for (int q = 0; q < 9; ++q) r[q] = ((q % 4 == 0) ? 1.f : 0.f) + s * K[q] + oc * KK[q];
   }
+}
+
+__global__ void pose_decode_kernel(const float *__restrict__ x, int type, float *__restrict__ out,
+                                   long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r[9];
+  decode_rotation(x + i * (type == SHAPY_POSE_CONT6D ? 6 : 3), type, r);
 #pragma unroll
   for (int q = 0; q < 9; ++q) out[i * 9 + q] = r[q];
+}
+
+// Everything between the regressor's parameter vectors and the SMPL-X kernels in ONE launch
+// (iterative_regressor.py:646-660 + the argument glue of SMPLX.forward, body_models.py:660-700):
+// decode the poses of ALL stages, build the zero-padded shape-coefficient rows of the last
+// stage and a contiguous copy of its camera parameters.
+struct PrepK {
+  const float *params;           // [S, B, P]
+  float *rot, *coeffs, *cam;     // [S, B, nj, 3, 3], [B, NBpad], [B, 3]
+  int S, B, P, pose_off, nj, pose_type, betas_off, n_betas, NBpad, cam_off;
+};
+
+__global__ void head_prepare_kernel(PrepK k) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n_rot = (long)k.S * k.B * k.nj, n_co = (long)k.B * k.NBpad;
+  const int per = k.pose_type == SHAPY_POSE_CONT6D ? 6 : 3;
+  if (i < n_rot) {
+    const int j = (int)(i % k.nj);
+    const long sb = i / k.nj;
+    float r[9];
+    decode_rotation(k.params + sb * k.P + k.pose_off + j * per, k.pose_type, r);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) k.rot[i * 9 + q] = r[q];
+  } else if (i < n_rot + n_co) {
+    const long q = i - n_rot;
+    const int c = (int)(q % k.NBpad);
+    const long b = q / k.NBpad;
+    k.coeffs[q] = c < k.n_betas ? k.params[((long)(k.S - 1) * k.B + b) * k.P + k.betas_off + c] : 0.f;
+  } else if (k.cam && i < n_rot + n_co + (long)k.B * 3) {
+    const long q = i - n_rot - n_co;
+    k.cam[q] = k.params[((long)(k.S - 1) * k.B + q / 3) * k.P + k.cam_off + q % 3];
+  }
 }
 
 __global__ void weak_persp_kernel(const float *__restrict__ pts, const float *__restrict__ scale,
@@ -416,11 +458,25 @@ extern "C" int shapy_regressor_affine_f32(const float *features, const float *Wf
   if ((F & 3) || P <= 0 || num_stages < 1) return SHAPY_EINVAL;
   float *t = params_out + (long)(num_stages - 1) * B * P;
   hipLaunchKernelGGL(regressor_feat_kernel, dim3((P + 3) / 4, (B + REG_RB - 1) / REG_RB), dim3(256),
-                     0, (hipStream_t)stream, features, Wf, bias, t, B, F, P);
+                     0, (hipStream_t)stream, features, Wf, bias, t, B, F, P, 0);
   SHAPY_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(regressor_stage_kernel, dim3(B), dim3(256), 3 * P * sizeof(float),
                      (hipStream_t)stream, Wp, mean_param, params_out, B, P, num_stages,
                      cond_per_body ? P : 0);
+  return (int)hipGetLastError();
+}
+
+// All stages in one launch: params_out[s] = W_all[s] feat + b_all[s]  (the host collapses
+// p_s = p_{s-1} + t + Wp p_{s-1}, p_0 = mean, t = Wf feat + b into W_all [S*P, F], b_all [S*P]
+// in float64; valid when every body starts from the same mean, i.e. cond is None).
+extern "C" int shapy_regressor_collapsed_f32(const float *features, const float *W_all,
+                                             const float *b_all, float *params_out, int B, int F,
+                                             int P, int num_stages, void *stream) {
+  if (B <= 0) return SHAPY_OK;
+  if ((F & 3) || P <= 0 || num_stages < 1) return SHAPY_EINVAL;
+  const int R = P * num_stages;
+  hipLaunchKernelGGL(regressor_feat_kernel, dim3((R + 3) / 4, (B + REG_RB - 1) / REG_RB), dim3(256),
+                     0, (hipStream_t)stream, features, W_all, b_all, params_out, B, F, R, P);
   return (int)hipGetLastError();
 }
 
@@ -473,6 +529,26 @@ extern "C" int shapy_pose_decode_f32(const float *pose, int pose_type, float *ro
   if (pose_type != SHAPY_POSE_CONT6D && pose_type != SHAPY_POSE_AXIS_ANGLE) return SHAPY_EINVAL;
   hipLaunchKernelGGL(pose_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, pose, pose_type, rot_out, (long)n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int shapy_head_prepare_f32(const float *params, int S, int B, int P, int pose_off,
+                                      int n_joints, int pose_type, int betas_off, int n_betas,
+                                      int NBpad, int cam_off, float *rot_out, float *coeffs_out,
+                                      float *cam_out, void *stream) {
+  if (S <= 0 || B <= 0) return SHAPY_OK;
+  if (pose_type != SHAPY_POSE_CONT6D && pose_type != SHAPY_POSE_AXIS_ANGLE) return SHAPY_EINVAL;
+  const int per = pose_type == SHAPY_POSE_CONT6D ? 6 : 3;
+  if (pose_off < 0 || pose_off + n_joints * per > P || betas_off < 0 || betas_off + n_betas > P ||
+      n_betas > NBpad || (cam_out && (cam_off < 0 || cam_off + 3 > P)))
+    return SHAPY_EINVAL;
+  PrepK k;
+  k.params = params; k.rot = rot_out; k.coeffs = coeffs_out; k.cam = cam_out;
+  k.S = S; k.B = B; k.P = P; k.pose_off = pose_off; k.nj = n_joints; k.pose_type = pose_type;
+  k.betas_off = betas_off; k.n_betas = n_betas; k.NBpad = NBpad; k.cam_off = cam_off;
+  const long total = (long)S * B * n_joints + (long)B * NBpad + (cam_out ? (long)B * 3 : 0);
+  hipLaunchKernelGGL(head_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, k);
   return (int)hipGetLastError();
 }
 

@@ -271,7 +271,11 @@ int conv2d_wino(ConvK k, int tm, hipStream_t s) {
   if (wb >= 0x7fffffffull) return SHAPY_EINVAL;
   k.wgt2_bytes = (unsigned)wb;
   k.nbx = k.Cout / 48;
-  if (tm == 0) tm = (long)((k.wino_tiles + 31) / 32) * k.nbx >= 1024 ? 2 : 1;
+  // measured on MI355X at B = 64 (profiles/conv_bench_r02b_winograd_tm1_tm2.txt): two tile groups
+  // win once the K loop is long enough to amortise the larger prologue (Cin >= 96: 192 -> 192
+  // @14x14 67 -> 57 us, 256 -> 48 @56x56 292 -> 272 us) and the grid still has >= 1.5 workgroups
+  // per CU; 48 -> 48 @56x56 (3 chunks) and 384 -> 384 @7x7 (256 workgroups) are faster with one
+  if (tm == 0) tm = (k.Cin >= 96 && (long)((k.wino_tiles + 31) / 32) * k.nbx >= 384) ? 2 : 1;
   k.nby = (k.wino_tiles + 16 * tm - 1) / (16 * tm);
   if (tm == 2)
     hipLaunchKernelGGL((conv_wino_kernel<3, 2>), dim3(k.nbx * k.nby), dim3(256), 0, s, k);

@@ -19,6 +19,8 @@
 //
 // This translation unit is compiled with -ffp-contract=off so that every float32 decision
 // (SAT tolerance tests, barycentric range tests) is bit-identical with the CPU oracle.
+#include <stdlib.h>
+
 #include "tri_tri.h"
 
 namespace shapy {
@@ -158,7 +160,7 @@ template <bool STAGED>
 __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
     const float *__restrict__ v_shaped, const int32_t *__restrict__ faces, int V, int F, int Fs,
     int CAP, Landmarks lm, int *__restrict__ counters, float *__restrict__ vol_partial,
-    float4 *__restrict__ points) {
+    float4 *__restrict__ points, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float sv[];
   __shared__ int queue[M2_QCAP];
   __shared__ int qn;
@@ -167,7 +169,9 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
   const int b = blockIdx.y, tid = threadIdx.x;
   const float *vb = v_shaped + (long)b * V * 3;
   int shift = 0;
-  if constexpr (STAGED) {
+  // dbg (SHAPY_MEASURE_DBG, tuning only): 1 = no scan loop, 2 = no candidate evaluation,
+  // 4 = no staging copy -- wrong results on purpose, to time the phases
+  if (STAGED && !(dbg & 4)) {
     // 16-byte copies: mesh b starts at byte b * V * 12, which is only 4-byte aligned; the LDS
     // image is shifted by the same phase so that both sides of the vector copy are aligned
     const int N = V * 3;
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
   int f = f_lo + tid;
   int i0 = 0, i1 = 0, i2 = 0;
   if (f < f_hi) { i0 = faces[f * 3]; i1 = faces[f * 3 + 1]; i2 = faces[f * 3 + 2]; }
+  if (dbg & 1) f = f_hi;
   while (f < f_hi) {
     const int fn = f + M2_THREADS;
     int n0 = 0, n1 = 0, n2 = 0;
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
   }
   __syncthreads();
   {
-    const int n = qn < M2_QCAP ? qn : M2_QCAP;
+    const int n = (dbg & 2) ? 0 : (qn < M2_QCAP ? qn : M2_QCAP);
     for (int p = tid; p < 2 * n; p += M2_THREADS) {
       const int c = queue[p >> 1];
       process(c >> 2, c & 3, p & 1, load_face(c >> 2));
@@ -278,13 +283,16 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
 
 // One wave per (mesh, plane): gather the <= 2 * MC points of the two plane triangles, bitonic
 // sort by (x, z, y) in LDS (the result is a pure function of the point SET: the atomic order of
-// the scan does not matter), Andrew's monotone chain in the (x, z) plane with float64
-// orientation tests, perimeter in 3-D (body_measurements.py:160-179).  One wave instead of one
-// workgroup per hull: the chain is serial either way, and 3,000 waves of 1,000 meshes are all
-// resident at once (<= 10 KB of LDS each).
+// the scan does not matter), drop exact duplicates (every mesh edge that crosses the plane is
+// reported by both triangles sharing it), then Andrew's monotone chain in the (x, z) plane with
+// float64 orientation tests -- the lower chain on lane 0 and the upper chain on lane 1 at the
+// same time, the two topmost stack points held in registers so that a step without a pop needs
+// no LDS round trip -- and the 3-D perimeter (body_measurements.py:160-179) as a wave
+// reduction over the hull edges.  One wave instead of one workgroup per hull: the chain is
+// serial either way, and the 3,000 waves of 1,000 meshes are all resident at once.
 // Overflow (more than MC hits of one plane triangle): the MC LOWEST face indices are kept, the
 // rule of the ascending-order CPU oracle -- deterministic as long as the scan could store all
-// hits (CAP = 2 MC slots per list); the excess is counted in *overflow either way.
+// hits (CAP >= 256 slots per list); the excess is counted in *overflow either way.
 __global__ __launch_bounds__(64) void measure_hull2_kernel(
     const float *__restrict__ v_shaped, const int32_t *__restrict__ faces, int V, int MC, int CAP,
     int NP, int n_slices, Landmarks lm, const int *__restrict__ counters,
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(64) void measure_hull2_kernel(
     float *__restrict__ out, int *__restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) float hl[];
   float *px = hl, *py = hl + NP, *pz = hl + 2 * NP;
-  int *stack = reinterpret_cast<int *>(hl + 3 * NP);           // NP + 1 entries
+  int *stk = reinterpret_cast<int *>(hl + 3 * NP);             // 2 chains x (NP + 1) indices
   const int pl = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const long list0 = ((long)b * 3 + pl) * 2;
   const int c0 = counters[list0], c1 = counters[list0 + 1];
@@ -339,32 +347,60 @@ __global__ __launch_bounds__(64) void measure_hull2_kernel(
       }
       __syncthreads();
     }
-  if (lane == 0) {
-    int n = 0;
-    while (n < npow && px[n] != INFINITY) ++n;
-    float perim = 0.f;
-    if (n >= 2) {
-      auto orient = [&](int o, int a, int c) -> double {
-        return ((double)px[a] - (double)px[o]) * ((double)pz[c] - (double)pz[o]) -
-               ((double)pz[a] - (double)pz[o]) * ((double)px[c] - (double)px[o]);
-      };
-      auto edge = [&](int a, int c) -> float {
-        const float dx = px[c] - px[a], dy = py[c] - py[a], dz = pz[c] - pz[a];
-        return sqrtf(dx * dx + dy * dy + dz * dz);
-      };
-      int m = 0;
-      for (int i = 0; i < n; ++i) {
-        while (m >= 2 && orient(stack[m - 2], stack[m - 1], i) <= 0.0) --m;
-        stack[m++] = i;
-      }
-      const int lower = m + 1;
-      for (int i = n - 2; i >= 0; --i) {
-        while (m >= lower && orient(stack[m - 2], stack[m - 1], i) <= 0.0) --m;
-        stack[m++] = i;
-      }
-      // stack[0..m-1] is the closed hull polygon (stack[m-1] == stack[0])
-      for (int i = 0; i + 1 < m; ++i) perim += edge(stack[i], stack[i + 1]);
+  // compact: valid entries that differ from their predecessor (in place: the destination of
+  // chunk c lies at or below its source and every earlier chunk has been consumed)
+  int n = 0;
+  for (int i0 = 0; i0 < npow; i0 += 64) {
+    const int i = i0 + lane;
+    const float x = px[i], y = py[i], z = pz[i];
+    bool keep = x != INFINITY;
+    if (keep && i > 0) keep = !(px[i - 1] == x && py[i - 1] == y && pz[i - 1] == z);
+    const unsigned long long mask = __ballot(keep);
+    __syncthreads();
+    if (keep) {
+      const int d = n + __popcll(mask & ((1ull << lane) - 1ull));
+      px[d] = x; py[d] = y; pz[d] = z;
     }
+    n += __popcll(mask);
+    __syncthreads();
+  }
+  // monotone chains: lane 0 walks left -> right (lower hull), lane 1 right -> left (upper hull)
+  int *st = stk + (lane & 1) * (NP + 1);
+  int m = 0;
+  if (lane < 2 && n >= 1) {
+    const int step = lane == 0 ? 1 : -1;
+    int i = lane == 0 ? 0 : n - 1;
+    double ox = 0, oz = 0, ax = 0, az = 0;          // stack[m-2], stack[m-1]
+    for (int it = 0; it < n; ++it, i += step) {
+      const double cx = (double)px[i], cz = (double)pz[i];
+      while (m >= 2 && (ax - ox) * (cz - oz) - (az - oz) * (cx - ox) <= 0.0) {
+        --m;
+        ax = ox; az = oz;
+        if (m >= 2) { const int q = st[m - 2]; ox = (double)px[q]; oz = (double)pz[q]; }
+      }
+      st[m++] = i;
+      ox = ax; oz = az; ax = cx; az = cz;
+    }
+  }
+  __syncthreads();
+  const int ml = __shfl(m, 0, 64), mu = __shfl(m, 1, 64);
+  // perimeter: lower edges then upper edges, one edge per lane and round
+  float perim = 0.f;
+  const int ne = (ml > 0 ? ml - 1 : 0) + (mu > 0 ? mu - 1 : 0);
+  for (int e0 = 0; e0 < ne; e0 += 64) {
+    const int e = e0 + lane;
+    float len = 0.f;
+    if (e < ne) {
+      const bool lower = e < ml - 1;
+      const int *s2 = stk + (lower ? 0 : NP + 1);
+      const int k = lower ? e : e - (ml - 1);
+      const int a = s2[k], c = s2[k + 1];
+      const float dx = px[c] - px[a], dy = py[c] - py[a], dz = pz[c] - pz[a];
+      len = sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+    perim += wave_reduce_sum(len);
+  }
+  if (lane == 0) {
     out[b * 5 + 2 + pl] = perim;
     if (pl == 0) {
       double vs = 0.0;
@@ -418,6 +454,11 @@ extern "C" int shapy_mesh_to_mesh_f32(const float *query, const float *target, i
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// slots per (mesh, plane, plane triangle) list: twice max_coll, at least 256 -- room to store
+// every hit of a list that overflows max_coll, so that the hull kernel can pick the max_coll
+// lowest faces deterministically
+static int measure_cap(int max_coll) { return 2 * max_coll > 256 ? 2 * max_coll : 256; }
+
 static bool measure_staged(int V) {
   return (size_t)V * 12 + 32 + M2_STATIC_LDS <= (size_t)M2_LDS_TOTAL;
 }
@@ -425,7 +466,7 @@ static bool measure_staged(int V) {
 extern "C" size_t shapy_body_measure_workspace_bytes(int B, int F, int max_coll) {
   return align_up((size_t)B * 6 * sizeof(int), 256) +
          align_up((size_t)B * M2_MAX_SLICES * sizeof(float), 256) +
-         (size_t)B * 6 * 2 * max_coll * sizeof(float4);
+         (size_t)B * 6 * measure_cap(max_coll) * sizeof(float4);
 }
 
 extern "C" int shapy_body_measure_f32(const float *v_shaped, const int32_t *faces, int B, int V,
@@ -443,7 +484,7 @@ extern "C" int shapy_body_measure_f32(const float *v_shaped, const int32_t *face
     lm.face[i] = lm_face_host[i];
     for (int k = 0; k < 3; ++k) lm.bc[i][k] = lm_bary_host[i * 3 + k];
   }
-  const int CAP = 2 * max_coll;
+  const int CAP = measure_cap(max_coll);
   char *w = (char *)workspace;
   int *counters = (int *)w;
   w += align_up((size_t)B * 6 * sizeof(int), 256);
@@ -452,6 +493,7 @@ extern "C" int shapy_body_measure_f32(const float *v_shaped, const int32_t *face
   float4 *pts = (float4 *)w;
   SHAPY_HIP_TRY(hipMemsetAsync(counters, 0, (size_t)B * 6 * sizeof(int), s));
   if (overflow_out) SHAPY_HIP_TRY(hipMemsetAsync(overflow_out, 0, sizeof(int32_t), s));
+  static const int dbg = getenv("SHAPY_MEASURE_DBG") ? atoi(getenv("SHAPY_MEASURE_DBG")) : 0;
   int S = 1;
   if (measure_staged(V)) {
     const size_t dyn = (size_t)V * 12 + 32;
@@ -462,19 +504,25 @@ extern "C" int shapy_body_measure_f32(const float *v_shaped, const int32_t *face
                                         M2_LDS_TOTAL - M2_STATIC_LDS));
       attr_set = true;
     }
-    hipLaunchKernelGGL(measure_scan2_kernel<true>, dim3(1, B), dim3(M2_THREADS), dyn, s, v_shaped,
-                       faces, V, F, F, CAP, lm, counters, vol, pts);
+    // small batches: several workgroups per mesh (each stages the whole vertex array -- the
+    // repeats hit L2 -- and scans a slice of the faces) so that the chip is not left idle
+    S = 256 / B;
+    if (S > 8) S = 8;
+    if (S < 1) S = 1;
+    const int Fs = (F + S - 1) / S;
+    hipLaunchKernelGGL(measure_scan2_kernel<true>, dim3(S, B), dim3(M2_THREADS), dyn, s, v_shaped,
+                       faces, V, F, Fs, CAP, lm, counters, vol, pts, dbg);
   } else {
     S = (F + 4095) / 4096;
     if (S > M2_MAX_SLICES) S = M2_MAX_SLICES;
     const int Fs = (F + S - 1) / S;
     hipLaunchKernelGGL(measure_scan2_kernel<false>, dim3(S, B), dim3(M2_THREADS), 0, s, v_shaped,
-                       faces, V, F, Fs, CAP, lm, counters, vol, pts);
+                       faces, V, F, Fs, CAP, lm, counters, vol, pts, dbg);
   }
   SHAPY_HIP_TRY(hipGetLastError());
   int NP = 2;
   while (NP < 2 * max_coll) NP <<= 1;
-  const size_t hull_lds = (size_t)(4 * NP + 1) * 4;
+  const size_t hull_lds = (size_t)(5 * NP + 2) * 4;
   hipLaunchKernelGGL(measure_hull2_kernel, dim3(3, B), dim3(64), hull_lds, s, v_shaped, faces, V,
                      max_coll, CAP, NP, S, lm, counters, vol, pts, out, overflow_out);
   return (int)hipGetLastError();

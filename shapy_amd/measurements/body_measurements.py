@@ -87,7 +87,7 @@ class BodyMeasurements(nn.Module):
         nbytes = lib.shapy_body_measure_workspace_bytes(B, F, mc)
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=v.device)
         out = torch.empty(B, 5, dtype=torch.float32, device=v.device)
-        overflow = torch.zeros(1, dtype=torch.int32, device=v.device)
+        overflow = torch.empty(1, dtype=torch.int32, device=v.device)     # zeroed by the call
         _lib.check(lib.shapy_body_measure_f32(
             _lib.ptr(v), _lib.ptr(faces_i32.contiguous()), B, V, F, lm_face, lm_bc,
             mc, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.ptr(overflow),

@@ -258,8 +258,6 @@ class SMPLX(VersionedWeights, nn.Module):
         """SMPLX.forward (body_models.py:628-767): poses are rotation matrices [B,k,3,3]."""
         device = self.shapedirs.device
         _lib.require_cuda(self.shapedirs, 'SMPLX buffers')
-        lib = _lib.load()
-        stream = _lib.current_stream()
         model_vars = [betas, global_rot, body_pose, transl, left_hand_pose, right_hand_pose,
                       jaw_pose, leye_pose, reye_pose, expression]
         B = 1
@@ -267,8 +265,6 @@ class SMPLX(VersionedWeights, nn.Module):
             if var is not None:
                 B = max(B, len(var))
         dm = self._device_model(device)
-        m = dm['struct']
-        V, J = dm['V'], dm['J']
         f32 = dict(dtype=torch.float32, device=device)
 
         def eye(n):
@@ -276,27 +272,63 @@ class SMPLX(VersionedWeights, nn.Module):
         parts = [(global_rot, 1), (body_pose, self.NUM_BODY_JOINTS), (jaw_pose, 1),
                  (leye_pose, 1), (reye_pose, 1), (left_hand_pose, self.NUM_HAND_JOINTS),
                  (right_hand_pose, self.NUM_HAND_JOINTS)]
-        full_pose = torch.cat([eye(n) if p is None else p.reshape(-1, n, 3, 3).to(**f32)
-                               for p, n in parts], dim=1).contiguous()
+        # joints after the last given part are identity inside the kernel (n_pose)
+        last = max([i for i, (p, _) in enumerate(parts) if p is not None], default=-1)
+        given = parts[:last + 1]
+        n_pose = sum(n for _, n in given)
+        if n_pose:
+            full_pose = torch.cat([eye(n) if p is None else p.reshape(-1, n, 3, 3).to(**f32)
+                                   for p, n in given], dim=1).contiguous()
+        else:
+            full_pose = torch.empty(B, 0, 3, 3, **f32)
         if betas is None:
             betas = torch.zeros([B, self.num_betas], **f32)
         coeffs = torch.zeros(B, dm['NBpad'], **f32)
         coeffs[:, :dm['nb']] = betas
+        coeffs_shape = None
         if expression is not None:
             coeffs[:, dm['nb']:dm['NB']] = expression
+            coeffs_shape = coeffs.clone()
+            coeffs_shape[:, dm['nb']:] = 0
+        out = self.forward_prepared(full_pose, coeffs, coeffs_shape=coeffs_shape, transl=transl,
+                                    get_skin=get_skin, return_shaped=return_shaped,
+                                    _shape_only=_shape_only)
+        if return_full_pose and not _shape_only:
+            J = dm['J']
+            out['full_pose'] = torch.cat([full_pose, eye(J - n_pose)], dim=1) if n_pose < J \
+                else full_pose
+        return out
 
+    def forward_prepared(self, pose, coeffs, coeffs_shape=None, camera=None, transl=None,
+                         get_skin=True, return_shaped=True, _shape_only=False):
+        """The numeric core of ``forward`` on prepared inputs -- no torch glue kernels:
+          pose    [B, n_pose, 3, 3] contiguous float32 rotation matrices of the first n_pose
+                  joints (global, body, jaw, eyes, hands order); the rest are identity
+          coeffs  [B, NBpad] float32: betas, then expression coefficients, zero padded
+          coeffs_shape  the same with the expression part zeroed, or None when there is no
+                  expression (``v_shaped`` is then the first GEMM's result)
+          camera  optional [B,3] raw weak-perspective parameters: the landmark kernel then also
+                  returns ``proj_joints`` = softplus(c0) * (xy + c[1:3]) and ``cam_scale`` [B,1]
+        ``shapy_head_prepare_f32`` produces pose / coeffs / camera for the regressor in one
+        launch (HMRLikeRegressor.forward)."""
+        device = self.shapedirs.device
+        lib = _lib.load()
+        stream = _lib.current_stream()
+        dm = self._device_model(device)
+        m = dm['struct']
+        V, J = dm['V'], dm['J']
+        B, n_pose = coeffs.shape[0], pose.shape[1]
+        f32 = dict(dtype=torch.float32, device=device)
         N = V * 3
         v_shaped_full = torch.empty(B, V, 3, **f32)
         self._gemm(lib, stream, coeffs, dm['NBpad'], dm['tensors']['shapedirs_t'], N, v_shaped_full,
                    bias=dm['tensors']['v_template'])
-        if expression is None:
+        if coeffs_shape is None:
             v_shaped = v_shaped_full
         else:
-            cb = coeffs.clone()
-            cb[:, dm['nb']:] = 0
             v_shaped = torch.empty(B, V, 3, **f32)
-            self._gemm(lib, stream, cb, dm['NBpad'], dm['tensors']['shapedirs_t'], N, v_shaped,
-                       bias=dm['tensors']['v_template'])
+            self._gemm(lib, stream, coeffs_shape, dm['NBpad'], dm['tensors']['shapedirs_t'], N,
+                       v_shaped, bias=dm['tensors']['v_template'])
         output = defaultdict(lambda: None, faces=self.faces)
         if return_shaped:
             output['v_shaped'] = v_shaped
@@ -309,7 +341,7 @@ class SMPLX(VersionedWeights, nn.Module):
         posed = torch.empty(B, J, 3, **f32)
         dyn_row = torch.empty(B, dtype=torch.int32, device=device)
         _lib.check(lib.shapy_smplx_pose_f32(
-            ctypes_byref(m), _lib.ptr(full_pose), _lib.POSE_ROTMAT, J, _lib.ptr(coeffs),
+            ctypes_byref(m), _lib.ptr(pose), _lib.POSE_ROTMAT, n_pose, _lib.ptr(coeffs),
             _lib.ptr(rot), _lib.ptr(pf), _lib.ptr(A), _lib.ptr(posed), _lib.ptr(dyn_row), B,
             stream), 'shapy_smplx_pose_f32')
         v_posed = torch.empty(B, V, 3, **f32)
@@ -320,10 +352,14 @@ class SMPLX(VersionedWeights, nn.Module):
                                             _lib.ptr(vertices), B, stream), 'shapy_smplx_skin_f32')
         n_out = J + m.n_static_lmk + (m.n_dyn_lmk if self.use_face_contour else 0)
         joints = torch.empty(B, n_out, 3, **f32)
+        # the fused projection is only valid when nothing edits the joints afterwards
+        fuse_cam = camera is not None and not self.use_joint_regressor and transl is None
+        proj = torch.empty(B, n_out, 2, **f32) if fuse_cam else None
+        scale = torch.empty(B, 1, **f32) if fuse_cam else None
         _lib.check(lib.shapy_smplx_joints_f32(
-            ctypes_byref(m), _lib.ptr(posed), _lib.ptr(vertices), _lib.ptr(dyn_row), None,
-            _lib.ptr(joints), None, None, B, int(self.use_face_contour), stream),
-            'shapy_smplx_joints_f32')
+            ctypes_byref(m), _lib.ptr(posed), _lib.ptr(vertices), _lib.ptr(dyn_row),
+            _lib.ptr(camera) if fuse_cam else None, _lib.ptr(joints), _lib.ptr(proj),
+            _lib.ptr(scale), B, int(self.use_face_contour), stream), 'shapy_smplx_joints_f32')
 
         if self.use_joint_regressor:
             Jn = self.extra_joint_regressor.shape[0]
@@ -336,14 +372,16 @@ class SMPLX(VersionedWeights, nn.Module):
             joints += transl.unsqueeze(dim=1)
             vertices += transl.unsqueeze(dim=1)
 
-        output['joints'] = KeypointTensor(
-            joints, source=self.name, keypoint_names=self.keypoint_names,
-            part_indices=self.parts, connections=self.connections,
-            part_connections=self.part_connections)
+        def kpt(t):
+            return KeypointTensor(t, source=self.name, keypoint_names=self.keypoint_names,
+                                  part_indices=self.parts, connections=self.connections,
+                                  part_connections=self.part_connections)
+        output['joints'] = kpt(joints)
+        if fuse_cam:
+            output['proj_joints'] = kpt(proj)
+            output['cam_scale'] = scale
         if get_skin:
             output['vertices'] = vertices
-        if return_full_pose:
-            output['full_pose'] = full_pose
         return output
 
 

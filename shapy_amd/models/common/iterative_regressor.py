@@ -149,12 +149,73 @@ class HMRLikeRegressor(nn.Module):
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._faces_i32 = {}
+        self.__dict__.pop('_fast_layout', None)
         return out
 
     def __getstate__(self):
         st = self.__dict__.copy()
         st['_faces_i32'] = {}
         return st
+
+    def _fast_head_layout(self):
+        """Parameter layout for the one-launch decode (shapy_head_prepare_f32), or None when the
+        configuration needs the generic path: the pose parameters must be [global_rot |
+        body_pose] back to back with the same parameterisation, only the last stage is posed,
+        and betas / camera are plain slices."""
+        lay = self.__dict__.get('_fast_layout', False)
+        if lay is not False:
+            return lay
+        lay = None
+        dec = [n for n in self.param_names if hasattr(self, f'{n}_decoder')]
+        if (self.pose_last_stage and dec == ['global_rot', 'body_pose']
+                and {'betas', 'camera'} <= set(self.param_names)
+                and self._slices['global_rot'][1] == self._slices['body_pose'][0]
+                and hasattr(self.model, 'forward_prepared')):
+            g, b = self.global_rot_decoder, self.body_pose_decoder
+            types = {'cont_rot_repr': (_lib.POSE_CONT6D, 6), 'aa': (_lib.POSE_AXIS_ANGLE, 3)}
+            if g.get_type() == b.get_type() and g.get_type() in types:
+                pose_type, per = types[g.get_type()]
+                a0, a1 = self._slices['global_rot'][0], self._slices['body_pose'][1]
+                import torch.nn.functional as F
+                from ..camera.camera_projection import WeakPerspectiveCamera
+                lay = dict(pose_type=pose_type, pose_off=a0, n_joints=(a1 - a0) // per,
+                           betas=self._slices['betas'], cam_off=self._slices['camera'][0],
+                           fuse_camera=(self.camera_scale_func is F.softplus
+                                        and isinstance(self.projection, WeakPerspectiveCamera)
+                                        and not self.projection.scale_first
+                                        and self._slices['camera'][1] - self._slices['camera'][0] == 3))
+                if lay['n_joints'] != 1 + self.model.NUM_BODY_JOINTS:
+                    lay = None
+        self.__dict__['_fast_layout'] = lay
+        return lay
+
+    def _decode_all_stages(self, lay):
+        out3 = self.regressor.last_output                       # [S,B,P]
+        S, B, P = out3.shape
+        dm = self.model._device_model(out3.device)
+        nj = lay['n_joints']
+        f32 = dict(dtype=torch.float32, device=out3.device)
+        rot_all = torch.empty(S, B, nj, 3, 3, **f32)
+        coeffs = torch.empty(B, dm['NBpad'], **f32)
+        cam = torch.empty(B, 3, **f32)
+        b0, b1 = lay['betas']
+        _lib.check(_lib.load().shapy_head_prepare_f32(
+            _lib.ptr(out3), S, B, P, lay['pose_off'], nj, lay['pose_type'], b0, min(b1 - b0, dm['nb']),
+            dm['NBpad'], lay['cam_off'], _lib.ptr(rot_all), _lib.ptr(coeffs), _lib.ptr(cam),
+            _lib.current_stream()), 'shapy_head_prepare_f32')
+        param_dicts = []
+        for s in range(S):
+            curr = self.flat_params_to_dict(out3[s])
+            d = {}
+            for key, val in curr.items():
+                if key == 'global_rot':
+                    d[key], d['raw_global_rot'] = rot_all[s][:, :1], val
+                elif key == 'body_pose':
+                    d[key], d['raw_body_pose'] = rot_all[s][:, 1:], val
+                else:
+                    d[key] = val
+            param_dicts.append(d)
+        return param_dicts, rot_all[S - 1], coeffs, cam
 
     def forward(self, images, targets=None, compute_losses=True, cond=None, extra_features=None,
                 **kwargs):
@@ -163,25 +224,41 @@ class HMRLikeRegressor(nn.Module):
         regr_output = self.regressor(features, cond=cond, extra_features=extra_features)
         parameters = [regr_output] if torch.is_tensor(regr_output) else regr_output[0]
 
-        param_dicts = []
-        for params in parameters:
-            curr = self.flat_params_to_dict(params)
-            out_dict = {}
-            for key, val in curr.items():
-                if hasattr(self, f'{key}_decoder'):
-                    out_dict[key] = getattr(self, f'{key}_decoder')(val)
-                    out_dict[f'raw_{key}'] = val.clone()
-                else:
-                    out_dict[key] = val
-            param_dicts.append(out_dict)
-        num_stages = len(param_dicts)
-        if self.pose_last_stage:
+        fused_camera = None
+        fast = self._fast_head_layout()
+        if fast is not None and torch.is_tensor(getattr(self.regressor, 'last_output', None)) \
+                and len(parameters) == self.regressor.last_output.shape[0] \
+                and parameters[0].data_ptr() == self.regressor.last_output.data_ptr():
+            # one launch for the decode of every stage + the SMPL-X argument glue
+            # (shapy_head_prepare_f32); raw_* are views of the parameter tensor (the reference
+            # returns clones of the same values, iterative_regressor.py:653-656)
+            param_dicts, rot_last, coeffs, cam = self._decode_all_stages(fast)
+            num_stages = len(param_dicts)
             merged_params = param_dicts[-1]
+            model_output = self.model.forward_prepared(
+                rot_last, coeffs, camera=cam if fast['fuse_camera'] else None, get_skin=True,
+                return_shaped=True)
+            if model_output.get('proj_joints') is not None:
+                fused_camera = (model_output.pop('proj_joints'), model_output.pop('cam_scale'))
         else:
-            merged_params = {key: torch.cat([pd[key] for pd in param_dicts if pd[key] is not None], dim=0)
-                             for key in param_dicts[0].keys()}
-
-        model_output = self.model(get_skin=True, return_shaped=True, **merged_params)
+            param_dicts = []
+            for params in parameters:
+                curr = self.flat_params_to_dict(params)
+                out_dict = {}
+                for key, val in curr.items():
+                    if hasattr(self, f'{key}_decoder'):
+                        out_dict[key] = getattr(self, f'{key}_decoder')(val)
+                        out_dict[f'raw_{key}'] = val.clone()
+                    else:
+                        out_dict[key] = val
+                param_dicts.append(out_dict)
+            num_stages = len(param_dicts)
+            if self.pose_last_stage:
+                merged_params = param_dicts[-1]
+            else:
+                merged_params = {key: torch.cat([pd[key] for pd in param_dicts if pd[key] is not None],
+                                                dim=0) for key in param_dicts[0].keys()}
+            model_output = self.model(get_skin=True, return_shaped=True, **merged_params)
 
         out_params = defaultdict(lambda: dict())
         for key in model_output:
@@ -203,10 +280,13 @@ class HMRLikeRegressor(nn.Module):
                     out_params[f'stage_{num_stages - 1:02d}'][key] = out_list[-1]
 
         camera_params = param_dicts[-1]['camera']
-        scale = self.camera_scale_func(camera_params[:, 0].reshape(-1, 1))
         translation = camera_params[:, 1:3]
-        est_joints3d = out_params[f'stage_{num_stages - 1:02d}']['joints']
-        proj_joints = self.projection(est_joints3d, scale=scale, translation=translation)
+        if fused_camera is not None:          # computed by the landmark kernel
+            proj_joints, scale = fused_camera
+        else:
+            scale = self.camera_scale_func(camera_params[:, 0].reshape(-1, 1))
+            est_joints3d = out_params[f'stage_{num_stages - 1:02d}']['joints']
+            proj_joints = self.projection(est_joints3d, scale=scale, translation=translation)
 
         out_params['proj_joints'] = proj_joints
         out_params['num_stages'] = num_stages

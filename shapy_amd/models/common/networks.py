@@ -158,9 +158,24 @@ class IterativeRegression(VersionedWeights, nn.Module):
             P = W.shape[0]
             if W.shape[1] != F + P:
                 raise ValueError(f'regressor expects {W.shape[1] - P} features, got {F}')
-            pk = dict(Wf=W[:, :F].float().contiguous().to(device),
-                      Wp=W[:, F:].float().contiguous().to(device),
-                      b=b.float().contiguous().to(device), P=P)
+            Wf64, Wp64 = W[:, :F], W[:, F:]
+            # the stages collapsed too (cond is None: p_0 = mean for every body):
+            #   p_s = A^s mean + (sum_{k<s} A^k) (Wf feat + b),  A = I + Wp      (float64)
+            A = torch.eye(P, dtype=torch.float64) + Wp64
+            mean64 = self.mean_param.detach().double().cpu().reshape(-1)[:P]
+            Ms, cs, M, Ak = [], [], torch.zeros(P, P, dtype=torch.float64), torch.eye(P, dtype=torch.float64)
+            for _ in range(self._num_stages):
+                M = M + Ak                     # sum_{k<s} A^k
+                Ak = A @ Ak                    # A^s
+                Ms.append(M.clone())
+                cs.append(Ak @ mean64)
+            W_all = torch.cat([m @ Wf64 for m in Ms], dim=0)
+            b_all = torch.cat([c + m @ b for c, m in zip(cs, Ms)], dim=0)
+            pk = dict(Wf=Wf64.float().contiguous().to(device),
+                      Wp=Wp64.float().contiguous().to(device),
+                      b=b.float().contiguous().to(device), P=P,
+                      W_all=W_all.float().contiguous().to(device),
+                      b_all=b_all.float().contiguous().to(device))
             self._packed[key] = pk
         return pk
 
@@ -180,6 +195,13 @@ class IterativeRegression(VersionedWeights, nn.Module):
         else:
             init, per_body = cond.reshape(B, -1)[:, :P].contiguous().float(), 1
         out = torch.empty(self._num_stages, B, P, dtype=torch.float32, device=features.device)
+        self.last_output = out                # [S,B,P]: the stages are views of one tensor
+        if cond is None:                      # one launch: all stages are affine in the features
+            _lib.check(lib.shapy_regressor_collapsed_f32(
+                _lib.ptr(features), _lib.ptr(pk['W_all']), _lib.ptr(pk['b_all']), _lib.ptr(out),
+                B, F, P, self._num_stages, _lib.current_stream()), 'shapy_regressor_collapsed_f32')
+            parameters = [out[s] for s in range(self._num_stages)]
+            return parameters, [parameters[0] - init.unsqueeze(0)]
         _lib.check(lib.shapy_regressor_affine_f32(
             _lib.ptr(features), _lib.ptr(pk['Wf']), _lib.ptr(pk['Wp']), _lib.ptr(pk['b']),
             _lib.ptr(init), _lib.ptr(out), B, F, P, self._num_stages, per_body,

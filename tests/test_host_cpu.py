@@ -173,6 +173,33 @@ def test_regressor_collapse_is_the_same_affine_map():
         MLP(8, 4, layers=[8], activation={'type': 'relu'}, normalization={'type': 'none'}).collapse()
 
 
+def test_regressor_stage_collapse_matches_the_iteration():
+    """The fully collapsed regressor (W_all, b_all of shapy_regressor_collapsed_f32) against the
+    layer-by-layer float32 iteration of the oracle (networks.py:536-592)."""
+    from oracle import body_np
+    from shapy_amd.models.common.networks import MLP, IterativeRegression
+    torch.manual_seed(1)
+    F, P = 64, 23
+    mlp = MLP(F + P, P, layers=[48, 48], activation={'type': 'none'},
+              normalization={'type': 'none'}, dropout=0.5, gain=1.0).eval()
+    with torch.no_grad():
+        mlp.output_layer.bias.normal_()
+    mean = torch.randn(1, P)
+    it = IterativeRegression(mlp, mean, num_stages=3).eval()
+    pk = it._pack(torch.device('cpu'), F)
+    feat = torch.randn(5, F)
+    got = (feat.double() @ pk['W_all'].double().t() + pk['b_all'].double()).view(5, 3, P)
+    layers = [(l.weight.detach().numpy(), l.bias.detach().numpy()) for l in mlp.linears()]
+    want = body_np.iterative_regression(feat.numpy(), mean.numpy().reshape(-1), layers, 3)
+    for s_ in range(3):
+        assert np.abs(got[:, s_].numpy() - want[s_]).max() < 5e-5 * np.abs(want[s_]).max()
+    # an in-place edit of a weight invalidates the packed copy (staleness key)
+    with torch.no_grad():
+        mlp.output_layer.bias.add_(1.0)
+    pk2 = it._pack(torch.device('cpu'), F)
+    assert pk2 is not pk and (pk2['b_all'] - pk['b_all']).abs().max() > 0.5
+
+
 def test_full_module_state_dict_layout(golden_dir):
     """Same keys and shapes as the reference SMPLXRegressor (checkpoint compatibility)."""
     import __graft_entry__ as ge
