@@ -101,7 +101,7 @@ typedef struct ShapyConv {
   const void *wgt_wino; /* NULL, or the Winograd F(2x2,3x3) transform of wgt for a float32
                          3x3 / stride 1 / pad 1 layer: U[p = 4i+j][Cin/16][Cout][16] float32,
                          U[i][j] = (G g G^T)[i][j] (shapy_amd/utils/winograd.py).  When given
-                         (and Cin % 16 == 0, Cout % 48 == 0, 16-byte aligned out / res / bias
+                         (and Cin % 16 == 0, Cout % 48 == 0 or % 64 == 0, 16-byte aligned out / res / bias
                          rows) the layer runs on csrc/conv_wino.hip: 2.25x fewer MFMAs, result
                          equal to the direct sum up to float32 rounding of the transforms.   */
 } ShapyConv;

@@ -40,7 +40,7 @@ __device__ __forceinline__ float quad_partner(float x) {
 }
 
 template <int NN, int TM>
-__global__ __launch_bounds__(256, (TM == 1 ? 3 : 2)) void conv_wino_kernel(ConvK p) {
+__global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino_kernel(ConvK p) {
   constexpr int N = 16 * NN, NCP = N + 4, N4 = N / 4, MT = 16 * TM;
   constexpr int PSTR = MT * 64;                       // bytes per position in a V buffer
   constexpr int LDS_V = 16 * PSTR;                    // V[16 pos][MT tiles][16 ch] f32
@@ -174,8 +174,40 @@ __global__ __launch_bounds__(256, (TM == 1 ? 3 : 2)) void conv_wino_kernel(ConvK
 
   const float *res = reinterpret_cast<const float *>(p.res);
   float *out = reinterpret_cast<float *>(p.out);
+  static_assert(16 * N4 <= 256, "one (tile, 4 channels) epilogue item per thread");
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt) {
+    // ---- epilogue item of this thread: (tile tl, channels col .. col + 3) ----
+    const int c4o = t % N4, tl = t / N4;
+    const int tile = m_blk + 16 * mt + tl;
+    const int col = n_blk + c4o * 4;
+    const bool active = t < 16 * N4 && tile < T && col < p.Cout;
+    bool ok[2][2];
+    long pix[2][2];
+    f32x4 rv[2][2];
+    {
+      const int tt_ = active ? tile : 0;
+      const int tx = tt_ % TW;
+      const int tq = tt_ / TW;
+      const int ty = tq % TH;
+      const int b = tq / TH;
+      const int oy = 2 * ty, ox = 2 * tx;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          ok[a][bb] = active && oy + a < H && ox + bb < W;
+          pix[a][bb] = ((long)(b * H + oy + a) * W + ox + bb);
+          // the residual is requested BEFORE the accumulators are parked: its latency hides
+          // behind the exchange (the B-fragment registers are free by now)
+          rv[a][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (res && ok[a][bb])
+            rv[a][bb] = *reinterpret_cast<const f32x4 *>(res + pix[a][bb] * p.res_ld + p.res_coff + col);
+        }
+    }
+    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && active) bias = *reinterpret_cast<const f32x4 *>(p.bias + col);
+
     // ---- park the accumulators of tile group mt: M[p][tile][channel] ----
     if (mt > 0) __syncthreads();             // the previous group's M has been consumed
     {
@@ -190,17 +222,8 @@ __global__ __launch_bounds__(256, (TM == 1 ? 3 : 2)) void conv_wino_kernel(ConvK
     }
     __syncthreads();
 
-    // ---- output transform + epilogue: thread (tile, 4 channels) ----
-    for (int it = t; it < 16 * N4; it += 256) {
-      const int c4o = it % N4, tl = it / N4;
-      const int tile = m_blk + 16 * mt + tl;
-      if (tile >= T) continue;
-      const int col = n_blk + c4o * 4;
-      if (col >= p.Cout) continue;
-      const int tx = tile % TW;
-      const int tq = tile / TW;
-      const int ty = tq % TH;
-      const int b = tq / TH;
+    // ---- output transform + bias + residual + ReLU + store ----
+    if (active) {
       const float *Mp = reinterpret_cast<const float *>(lds) + tl * NCP + c4o * 4;
       f32x4 tt[4][2];
 #pragma unroll
@@ -212,39 +235,18 @@ __global__ __launch_bounds__(256, (TM == 1 ? 3 : 2)) void conv_wino_kernel(ConvK
         tt[i][0] = (m0 + m1) + m2;             // M A
         tt[i][1] = (m1 - m2) - m3;
       }
-      f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bias = *reinterpret_cast<const f32x4 *>(p.bias + col);
       f32x4 y[2][2];
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb) {
         y[0][bb] = ((tt[0][bb] + tt[1][bb]) + tt[2][bb]) + bias;      // A^T (M A)
         y[1][bb] = ((tt[1][bb] - tt[2][bb]) - tt[3][bb]) + bias;
       }
-      const int oy = 2 * ty, ox = 2 * tx;
-      bool ok[2][2];
-      long pix[2][2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          ok[a][bb] = oy + a < H && ox + bb < W;
-          pix[a][bb] = ((long)(b * H + oy + a) * W + ox + bb);
-        }
-      if (res) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int bb = 0; bb < 2; ++bb)
-            if (ok[a][bb])
-              y[a][bb] +=
-                  *reinterpret_cast<const f32x4 *>(res + pix[a][bb] * p.res_ld + p.res_coff + col);
-      }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
           if (!ok[a][bb]) continue;
-          f32x4 v = y[a][bb];
+          f32x4 v = y[a][bb] + rv[a][bb];
           if (p.relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -257,7 +259,8 @@ __global__ __launch_bounds__(256, (TM == 1 ? 3 : 2)) void conv_wino_kernel(ConvK
 
 bool conv_wino_eligible(const ConvK &k) {
   return k.wgt2 != nullptr && k.ks == 3 && k.stride == 1 && k.pad == 1 && k.ups == 1 &&
-         k.Cin % 16 == 0 && k.Cout % 48 == 0 && k.vec4 && k.Ho == k.Hi && k.Wo == k.Wi &&
+         k.Cin % 16 == 0 && (k.Cout % 48 == 0 || k.Cout % 64 == 0) && k.vec4 && k.Ho == k.Hi &&
+         k.Wo == k.Wi &&
          (!k.bias || ((uintptr_t)k.bias & 15) == 0);
 }
 
@@ -270,14 +273,18 @@ int conv2d_wino(ConvK k, int tm, hipStream_t s) {
   const unsigned long long wb = 64ull * k.Cin * k.Cout;        // 16 positions x f32
   if (wb >= 0x7fffffffull) return SHAPY_EINVAL;
   k.wgt2_bytes = (unsigned)wb;
-  k.nbx = k.Cout / 48;
+  const int nn = k.Cout % 48 == 0 ? 3 : 4;            // 48- or 64-channel N tiles
+  k.nbx = k.Cout / (16 * nn);
   // measured on MI355X at B = 64 (profiles/conv_bench_r02b_winograd_tm1_tm2.txt): two tile groups
   // win once the K loop is long enough to amortise the larger prologue (Cin >= 96: 192 -> 192
   // @14x14 67 -> 57 us, 256 -> 48 @56x56 292 -> 272 us) and the grid still has >= 1.5 workgroups
   // per CU; 48 -> 48 @56x56 (3 chunks) and 384 -> 384 @7x7 (256 workgroups) are faster with one
   if (tm == 0) tm = (k.Cin >= 96 && (long)((k.wino_tiles + 31) / 32) * k.nbx >= 384) ? 2 : 1;
+  if (nn == 4) tm = 1;                                 // 64 accumulator + 64 B-fragment registers
   k.nby = (k.wino_tiles + 16 * tm - 1) / (16 * tm);
-  if (tm == 2)
+  if (nn == 4)
+    hipLaunchKernelGGL((conv_wino_kernel<4, 1>), dim3(k.nbx * k.nby), dim3(256), 0, s, k);
+  else if (tm == 2)
     hipLaunchKernelGGL((conv_wino_kernel<3, 2>), dim3(k.nbx * k.nby), dim3(256), 0, s, k);
   else
     hipLaunchKernelGGL((conv_wino_kernel<3, 1>), dim3(k.nbx * k.nby), dim3(256), 0, s, k);

@@ -132,14 +132,6 @@ __device__ __forceinline__ void measure_candidate(const Tri &t, float h, int f, 
   points[list * CAP + slot] = pt;
 }
 
-// out-of-line copy for the queue-overflow path of the scan loop (never taken for a body): keeps
-// the SAT code's registers out of the streaming loop
-__device__ __noinline__ void measure_candidate_noinline(const Tri &t, float h, int f, long list,
-                                                        int qi, int CAP, int *counters,
-                                                        float4 *points) {
-  measure_candidate(t, h, f, list, qi, CAP, counters, points);
-}
-
 constexpr int M2_THREADS = 1024;            // 16 waves: one workgroup owns a CU's LDS
 constexpr int M2_QCAP = 4096;               // candidate queue entries (face * 4 + plane)
 constexpr int M2_MAX_SLICES = 16;
@@ -160,7 +152,7 @@ template <bool STAGED>
 __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
     const float *__restrict__ v_shaped, const int32_t *__restrict__ faces, int V, int F, int Fs,
     int CAP, Landmarks lm, int *__restrict__ counters, float *__restrict__ vol_partial,
-    float4 *__restrict__ points, int dbg) {
+    float4 *__restrict__ points, int *__restrict__ overflow, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float sv[];
   __shared__ int queue[M2_QCAP];
   __shared__ int qn;
@@ -219,48 +211,49 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
   auto process = [&](int f, int pl, int qi, const Tri &t) {
     measure_candidate(t, hs[pl], f, ((long)b * 3 + pl) * 2 + qi, qi, CAP, counters, points);
   };
-  auto process_slow = [&](int f, int pl, int qi, const Tri &t) {
-    measure_candidate_noinline(t, hs[pl], f, ((long)b * 3 + pl) * 2 + qi, qi, CAP, counters, points);
-  };
-
   // The scan runs without barriers (every wave streams its faces at its own pace; the face
-  // indices of the next iteration are in flight while this one is evaluated).  A candidate that
-  // does not fit into the queue any more (> 4096 per mesh slice: not a body) is evaluated on
-  // the spot by the thread that found it.
+  // indices of the next iteration are in flight while this one is evaluated).  Candidates
+  // beyond the queue capacity (> 4096 per mesh slice: not a body -- a body has ~450) are
+  // dropped and reported through *overflow like hits beyond max_collisions.
   const int f_lo = blockIdx.x * Fs, f_hi = min(F, f_lo + Fs);
   double vol = 0.0;
+  int dropped = 0;
+  const float h0 = hs[0], h1 = hs[1], h2 = hs[2];
   int f = f_lo + tid;
   int i0 = 0, i1 = 0, i2 = 0;
   if (f < f_hi) { i0 = faces[f * 3]; i1 = faces[f * 3 + 1]; i2 = faces[f * 3 + 2]; }
   if (dbg & 1) f = f_hi;
   while (f < f_hi) {
     const int fn = f + M2_THREADS;
+    const float x0 = vtx(i0, 0), y0 = vtx(i0, 1), z0 = vtx(i0, 2);
+    const float x1 = vtx(i1, 0), y1 = vtx(i1, 1), z1 = vtx(i1, 2);
+    const float x2 = vtx(i2, 0), y2 = vtx(i2, 1), z2 = vtx(i2, 2);
+    // next face's indices: requested once this face's gathers are on their way, so that the
+    // request overlaps the arithmetic below (hipcc waits for ALL outstanding loads before the
+    // first use of a loop-carried load result, so it may not be issued any earlier)
     int n0 = 0, n1 = 0, n2 = 0;
     if (fn < f_hi) { n0 = faces[fn * 3]; n1 = faces[fn * 3 + 1]; n2 = faces[fn * 3 + 2]; }
-    Tri t;
-    t.v0 = v3(vtx(i0, 0), vtx(i0, 1), vtx(i0, 2));
-    t.v1 = v3(vtx(i1, 0), vtx(i1, 1), vtx(i1, 2));
-    t.v2 = v3(vtx(i2, 0), vtx(i2, 1), vtx(i2, 2));
     // compute_mass (body_measurements.py:201-215), term order as written there
-    const float x0 = t.v0.x, y0 = t.v0.y, z0 = t.v0.z, x1 = t.v1.x, y1 = t.v1.y, z1 = t.v1.z,
-                x2 = t.v2.x, y2 = t.v2.y, z2 = t.v2.z;
     const float vv = -x2 * y1 * z0 + x1 * y2 * z0 + x2 * y0 * z1 - x0 * y2 * z1 - x1 * y0 * z2 +
                      x0 * y1 * z2;
     vol += (double)vv;
     const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
+    // the y part of the AABB test against the three plane heights
+    const int mask = (int)(ymin <= h0 && ymax >= h0) | ((int)(ymin <= h1 && ymax >= h1) << 1) |
+                     ((int)(ymin <= h2 && ymax >= h2) << 2);
+    if (mask) {
+      int slot = atomicAdd(&qn, __popc(mask));
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      if (ymin <= hs[pl] && ymax >= hs[pl]) {        // the y part of the AABB test
-        const int slot = atomicAdd(&qn, 1);
-        if (slot < M2_QCAP) {
-          queue[slot] = f * 4 + pl;
-        } else {
-          process_slow(f, pl, 0, t);
-          process_slow(f, pl, 1, t);
+      for (int pl = 0; pl < 3; ++pl)
+        if (mask & (1 << pl)) {
+          if (slot < M2_QCAP) queue[slot] = f * 4 + pl;
+          else ++dropped;
+          ++slot;
         }
-      }
+    }
     f = fn; i0 = n0; i1 = n1; i2 = n2;
   }
+  if (dropped && overflow) atomicAdd(overflow, dropped);
   __syncthreads();
   {
     const int n = (dbg & 2) ? 0 : (qn < M2_QCAP ? qn : M2_QCAP);
@@ -281,6 +274,66 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
   }
 }
 
+// Bitonic sort of 64 * E points held in registers, element e = lane * E + r, ascending by
+// (x, z, y).  Compare-exchange distances below E stay inside a lane (register swaps); the others
+// exchange whole points with lane ^ (j / E) through __shfl_xor.  512 points: 24 in-register and
+// 21 cross-lane steps -- no LDS round trips and no barriers (the LDS version of the same
+// network spent ~45 us per hull on them).
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort(float (&x)[E], float (&z)[E], float (&y)[E],
+                                                  int lane) {
+  constexpr int N = 64 * E;
+  // stages (k) and cross-lane steps (j >= E) are run-time loops -- a fully unrolled network
+  // (45 steps x E points) spilled hundreds of registers; the in-register steps (j < E) index
+  // the point arrays with compile-time constants
+#pragma unroll 1
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll 1
+    for (int j = k >> 1; j >= E; j >>= 1) {
+      const int lm = j / E;
+      const bool lower = (lane & lm) == 0;
+      const bool up = ((lane * E) & k) == 0;        // k >= 2 E here: the same for all r
+#pragma unroll
+      for (int r = 0; r < E; ++r) {
+        const float ox = __shfl_xor(x[r], lm, 64), oz = __shfl_xor(z[r], lm, 64),
+                    oy = __shfl_xor(y[r], lm, 64);
+        const bool o_lt = ox < x[r] || (ox == x[r] && (oz < z[r] || (oz == z[r] && oy < y[r])));
+        const bool m_lt = x[r] < ox || (x[r] == ox && (z[r] < oz || (z[r] == oz && y[r] < oy)));
+        // the lower index of a pair keeps the smaller point in an ascending block
+        if ((lower == up) ? o_lt : m_lt) { x[r] = ox; z[r] = oz; y[r] = oy; }
+      }
+    }
+#pragma unroll
+    for (int j = E / 2; j > 0; j >>= 1) {
+      if (j < k) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          if ((r & j) == 0) {
+            const int q = r | j;
+            const bool up = ((lane * E + r) & k) == 0;
+            const bool gt = x[r] > x[q] || (x[r] == x[q] && (z[r] > z[q] || (z[r] == z[q] && y[r] > y[q])));
+            if (gt == up) {
+              const float tx = x[r], tz = z[r], ty = y[r];
+              x[r] = x[q]; z[r] = z[q]; y[r] = y[q];
+              x[q] = tx; z[q] = tz; y[q] = ty;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int E>
+__device__ __forceinline__ void hull_sort_in_registers(float *px, float *py, float *pz, int lane) {
+  float x[E], z[E], y[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) { x[r] = px[lane * E + r]; z[r] = pz[lane * E + r]; y[r] = py[lane * E + r]; }
+  wave_bitonic_sort<E>(x, z, y, lane);
+#pragma unroll
+  for (int r = 0; r < E; ++r) { px[lane * E + r] = x[r]; pz[lane * E + r] = z[r]; py[lane * E + r] = y[r]; }
+}
+
 // One wave per (mesh, plane): gather the <= 2 * MC points of the two plane triangles, bitonic
 // sort by (x, z, y) in LDS (the result is a pure function of the point SET: the atomic order of
 // the scan does not matter), drop exact duplicates (every mesh edge that crosses the plane is
@@ -293,7 +346,7 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
 // Overflow (more than MC hits of one plane triangle): the MC LOWEST face indices are kept, the
 // rule of the ascending-order CPU oracle -- deterministic as long as the scan could store all
 // hits (CAP >= 256 slots per list); the excess is counted in *overflow either way.
-__global__ __launch_bounds__(64) void measure_hull2_kernel(
+__global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
     const float *__restrict__ v_shaped, const int32_t *__restrict__ faces, int V, int MC, int CAP,
     int NP, int n_slices, Landmarks lm, const int *__restrict__ counters,
     const float *__restrict__ vol_partial, const float4 *__restrict__ points,
@@ -309,7 +362,7 @@ __global__ __launch_bounds__(64) void measure_hull2_kernel(
   if (lane == 0 && overflow && (c0 > MC || c1 > MC)) atomicAdd(overflow, (c0 - n0) + (c1 - n1));
   int npow = 2;
   while (npow < n0 + n1) npow <<= 1;
-  for (int i = lane; i < npow; i += 64) { px[i] = INFINITY; py[i] = 0.f; pz[i] = INFINITY; }
+  for (int i = lane; i < NP; i += 64) { px[i] = INFINITY; py[i] = 0.f; pz[i] = INFINITY; }
   __syncthreads();
 #pragma unroll
   for (int qi = 0; qi < 2; ++qi) {
@@ -330,30 +383,40 @@ __global__ __launch_bounds__(64) void measure_hull2_kernel(
     }
   }
   __syncthreads();
-  // bitonic sort by (x, z, y): invalid (+inf) entries sink to the end
-  for (int k = 2; k <= npow; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = lane; i < npow; i += 64) {
-        const int l = i ^ j;
-        if (l > i) {
-          const bool up = (i & k) == 0;
-          const float ax = px[i], az = pz[i], ay = py[i], bx = px[l], bz = pz[l], by = py[l];
-          const bool gt = ax > bx || (ax == bx && (az > bz || (az == bz && ay > by)));
-          if (gt == up) {
-            px[i] = bx; pz[i] = bz; py[i] = by;
-            px[l] = ax; pz[l] = az; py[l] = ay;
+  // sort by (x, z, y): invalid (+inf) entries sink to the end
+  if (npow <= 256 && NP >= 256) {
+    hull_sort_in_registers<4>(px, py, pz, lane);
+    npow = 256;
+    __syncthreads();
+  } else if (npow <= 512 && NP >= 512) {
+    hull_sort_in_registers<8>(px, py, pz, lane);
+    npow = 512;
+    __syncthreads();
+  } else {                                  // max_collisions > 256: the same network through LDS
+    for (int k = 2; k <= npow; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = lane; i < npow; i += 64) {
+          const int l = i ^ j;
+          if (l > i) {
+            const bool up = (i & k) == 0;
+            const float ax = px[i], az = pz[i], ay = py[i], bx = px[l], bz = pz[l], by = py[l];
+            const bool gt = ax > bx || (ax == bx && (az > bz || (az == bz && ay > by)));
+            if (gt == up) {
+              px[i] = bx; pz[i] = bz; py[i] = by;
+              px[l] = ax; pz[l] = az; py[l] = ay;
+            }
           }
         }
+        __syncthreads();
       }
-      __syncthreads();
-    }
+  }
   // compact: valid entries that differ from their predecessor (in place: the destination of
   // chunk c lies at or below its source and every earlier chunk has been consumed)
   int n = 0;
   for (int i0 = 0; i0 < npow; i0 += 64) {
     const int i = i0 + lane;
     const float x = px[i], y = py[i], z = pz[i];
-    bool keep = x != INFINITY;
+    bool keep = i < npow && x != INFINITY;
     if (keep && i > 0) keep = !(px[i - 1] == x && py[i - 1] == y && pz[i - 1] == z);
     const unsigned long long mask = __ballot(keep);
     __syncthreads();
@@ -511,16 +574,16 @@ extern "C" int shapy_body_measure_f32(const float *v_shaped, const int32_t *face
     if (S < 1) S = 1;
     const int Fs = (F + S - 1) / S;
     hipLaunchKernelGGL(measure_scan2_kernel<true>, dim3(S, B), dim3(M2_THREADS), dyn, s, v_shaped,
-                       faces, V, F, Fs, CAP, lm, counters, vol, pts, dbg);
+                       faces, V, F, Fs, CAP, lm, counters, vol, pts, overflow_out, dbg);
   } else {
     S = (F + 4095) / 4096;
     if (S > M2_MAX_SLICES) S = M2_MAX_SLICES;
     const int Fs = (F + S - 1) / S;
     hipLaunchKernelGGL(measure_scan2_kernel<false>, dim3(S, B), dim3(M2_THREADS), 0, s, v_shaped,
-                       faces, V, F, Fs, CAP, lm, counters, vol, pts, dbg);
+                       faces, V, F, Fs, CAP, lm, counters, vol, pts, overflow_out, dbg);
   }
   SHAPY_HIP_TRY(hipGetLastError());
-  int NP = 2;
+  int NP = 64;                              // >= one wave's worth: the compaction reads whole chunks
   while (NP < 2 * max_coll) NP <<= 1;
   const size_t hull_lds = (size_t)(5 * NP + 2) * 4;
   hipLaunchKernelGGL(measure_hull2_kernel, dim3(3, B), dim3(64), hull_lds, s, v_shaped, faces, V,

@@ -169,8 +169,9 @@ class IterativeRegression(VersionedWeights, nn.Module):
                 Ak = A @ Ak                    # A^s
                 Ms.append(M.clone())
                 cs.append(Ak @ mean64)
-            W_all = torch.cat([m @ Wf64 for m in Ms], dim=0)
-            b_all = torch.cat([c + m @ b for c, m in zip(cs, Ms)], dim=0)
+            # block S (one more "stage"): the stage-0 delta p_1 - mean that forward() returns
+            W_all = torch.cat([m @ Wf64 for m in Ms] + [Ms[0] @ Wf64], dim=0)
+            b_all = torch.cat([c + m @ b for c, m in zip(cs, Ms)] + [cs[0] + Ms[0] @ b - mean64], dim=0)
             pk = dict(Wf=Wf64.float().contiguous().to(device),
                       Wp=Wp64.float().contiguous().to(device),
                       b=b.float().contiguous().to(device), P=P,
@@ -194,14 +195,16 @@ class IterativeRegression(VersionedWeights, nn.Module):
             init, per_body = self.mean_param.reshape(-1).contiguous().float(), 0
         else:
             init, per_body = cond.reshape(B, -1)[:, :P].contiguous().float(), 1
-        out = torch.empty(self._num_stages, B, P, dtype=torch.float32, device=features.device)
-        self.last_output = out                # [S,B,P]: the stages are views of one tensor
+        S = self._num_stages
         if cond is None:                      # one launch: all stages are affine in the features
+            out = torch.empty(S + 1, B, P, dtype=torch.float32, device=features.device)
             _lib.check(lib.shapy_regressor_collapsed_f32(
                 _lib.ptr(features), _lib.ptr(pk['W_all']), _lib.ptr(pk['b_all']), _lib.ptr(out),
-                B, F, P, self._num_stages, _lib.current_stream()), 'shapy_regressor_collapsed_f32')
-            parameters = [out[s] for s in range(self._num_stages)]
-            return parameters, [parameters[0] - init.unsqueeze(0)]
+                B, F, P, S + 1, _lib.current_stream()), 'shapy_regressor_collapsed_f32')
+            self.last_output = out[:S]        # [S,B,P]: the stages are views of one tensor
+            return [out[s] for s in range(S)], [out[S]]
+        out = torch.empty(S, B, P, dtype=torch.float32, device=features.device)
+        self.last_output = out
         _lib.check(lib.shapy_regressor_affine_f32(
             _lib.ptr(features), _lib.ptr(pk['Wf']), _lib.ptr(pk['Wp']), _lib.ptr(pk['b']),
             _lib.ptr(init), _lib.ptr(out), B, F, P, self._num_stages, per_body,

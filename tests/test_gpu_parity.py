@@ -134,6 +134,9 @@ WINO_CASES = [
     (1, 14, 14, 192, 192, True, True),
     (1, 7, 7, 384, 384, True, True),
     (2, 56, 56, 48, 48, True, True),
+    (2, 12, 12, 64, 64, True, True),       # 64-channel N tiles (layer1's 64 -> 64)
+    (1, 7, 7, 512, 512, False, True),      # the head's 512 -> 512
+    (2, 9, 9, 32, 128, True, False),
 ]
 
 

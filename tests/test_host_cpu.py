@@ -173,6 +173,39 @@ def test_regressor_collapse_is_the_same_affine_map():
         MLP(8, 4, layers=[8], activation={'type': 'relu'}, normalization={'type': 'none'}).collapse()
 
 
+def test_weight_caches_are_keyed_on_parameter_versions(hrnet):
+    """an in-place edit of a parameter or buffer must invalidate the folded blob /
+    graphs (HighResolutionNet._compile compares _weights_version())."""
+    v0 = hrnet._weights_version()
+    assert hrnet._weights_version() == v0
+    with torch.no_grad():
+        hrnet.conv1.weight.mul_(1.0)                 # any in-place op bumps the version counter
+    v1 = hrnet._weights_version()
+    assert v1 != v0
+    hrnet.bn1.running_mean.add_(0.0)
+    assert hrnet._weights_version() != v1
+    hrnet.invalidate()
+    assert hrnet.__dict__['_ver_tensors'] is None and hrnet._engine == {}
+
+
+def test_winograd_plan_covers_the_3x3_stride1_layers(hrnet):
+    from shapy_amd.utils import winograd
+    hrnet.conv_algo = 'winograd'
+    P = hrnet._build_plan(64, 64)
+    n3 = [o for o in P.ops if o['type'] == 0 and o['ksize'] == 3 and o['stride'] == 1]
+    nw = [o for o in P.ops if o.get('wino_off', -1) >= 0]
+    assert len(nw) == len(n3) and len(nw) > 200          # every 3x3 / stride-1 conv of HRNet-W48
+    hrnet.conv_algo = 'direct'
+    assert all(o.get('wino_off', -1) < 0 for o in hrnet._build_plan(64, 64).ops)
+    hrnet.conv_algo = 'winograd'
+    # filter transform: U[4i+j] = (G g G^T)[i][j], K-chunked layout
+    w = np.random.default_rng(0).standard_normal((48, 3, 3, 32)).astype(np.float32)
+    u = winograd.transform_filters(w)
+    assert u.shape == (16, 2, 48, 16)
+    g = w[5, :, :, 19].astype(np.float64)
+    np.testing.assert_allclose(u[:, 1, 5, 3].reshape(4, 4), winograd.G @ g @ winograd.G.T, rtol=1e-6)
+
+
 def test_regressor_stage_collapse_matches_the_iteration():
     """The fully collapsed regressor (W_all, b_all of shapy_regressor_collapsed_f32) against the
     layer-by-layer float32 iteration of the oracle (networks.py:536-592)."""
@@ -188,11 +221,13 @@ def test_regressor_stage_collapse_matches_the_iteration():
     it = IterativeRegression(mlp, mean, num_stages=3).eval()
     pk = it._pack(torch.device('cpu'), F)
     feat = torch.randn(5, F)
-    got = (feat.double() @ pk['W_all'].double().t() + pk['b_all'].double()).view(5, 3, P)
+    got = (feat.double() @ pk['W_all'].double().t() + pk['b_all'].double()).view(5, 4, P)
     layers = [(l.weight.detach().numpy(), l.bias.detach().numpy()) for l in mlp.linears()]
     want = body_np.iterative_regression(feat.numpy(), mean.numpy().reshape(-1), layers, 3)
     for s_ in range(3):
         assert np.abs(got[:, s_].numpy() - want[s_]).max() < 5e-5 * np.abs(want[s_]).max()
+    d0 = want[0] - mean.numpy()                      # block 3: the stage-0 delta
+    assert np.abs(got[:, 3].numpy() - d0).max() < 5e-5 * np.abs(d0).max()
     # an in-place edit of a weight invalidates the packed copy (staleness key)
     with torch.no_grad():
         mlp.output_layer.bias.add_(1.0)

@@ -20,12 +20,26 @@ out, dt, algo = sys.argv[1], sys.argv[2], sys.argv[3]
 FORWARDS = 3          # --steps 2 --warmup 1; every forward = 330 backbone convs + the SMPL-X GEMMs
 tot = collections.defaultdict(float)
 n = collections.defaultdict(int)
+per = collections.defaultdict(dict)          # dispatch order within its pass -> counters
 for f in glob.glob(out + '/*/**/*counter_collection.csv', recursive=True):
-    for r in csv.DictReader(open(f)):
-        if 'conv_' not in r['Kernel_Name']:
-            continue
+    rows = [r for r in csv.DictReader(open(f)) if 'conv_' in r['Kernel_Name']]
+    order = {}
+    for r in sorted(rows, key=lambda r: int(r['Dispatch_Id'])):
         tot[r['Counter_Name']] += float(r['Counter_Value'])
         n[r['Counter_Name']] += 1
+        k = order.setdefault(r['Counter_Name'], [0])
+        key = k[0] % 333                        # position inside one forward (333 conv launches)
+        k[0] += 1
+        if r['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            e = per[key]
+            e['kernel'] = r['Kernel_Name'].replace('void shapy::', '').split('(')[0]
+            e['grid'] = r.get('Grid_Size', '')
+            e[r['Counter_Name']] = e.get(r['Counter_Name'], 0.0) + float(r['Counter_Value']) * 1024 / 3
+with open(out + '_per_launch.csv', 'w') as fh:
+    fh.write('launch,kernel,grid,read_bytes_x2,write_bytes\n')
+    for key in sorted(per):
+        e = per[key]
+        fh.write(f"{key},{e.get('kernel')},{e.get('grid')},{2 * e.get('FETCH_SIZE', 0):.0f},{e.get('WRITE_SIZE', 0):.0f}\n")
 fw = {k: float(FORWARDS) for k in n}
 res = {'note': 'tools/pmc_hbm_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / '
                'SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE in separate passes over python bench.py '

@@ -13,10 +13,10 @@ sys.path.insert(0, osp.dirname(osp.dirname(osp.abspath(__file__))))
 from shapy_amd.utils import winograd as wg      # noqa: E402
 
 f32 = np.float32
-NN, N, NCP = 3, 48, 52
 
 
-def emulate_workgroup(x, u, bias, wg_m, wg_n, TM=1):
+def emulate_workgroup(x, u, bias, wg_m, wg_n, TM=1, NN=3):
+    N, NCP = 16 * NN, 16 * NN + 4
     B, H, W, Cin = x.shape
     Cout = u.shape[2]
     TW, TH = (W + 1) // 2, (H + 1) // 2
@@ -99,8 +99,8 @@ def emulate_workgroup(x, u, bias, wg_m, wg_n, TM=1):
                         for rg in range(4):
                             M[((4 * wave + pp) * 16 + 4 * kq + rg) * NCP + n * 16 + l15] = \
                                 acc[wave, lane, pp, mt, n, rg]
-        for it in range(16 * 12):
-            c4o, tl = it % 12, it // 12
+        for it in range(16 * (N // 4)):
+            c4o, tl = it % (N // 4), it // (N // 4)
             tile = m_blk + 16 * mt + tl
             if tile >= T:
                 continue
@@ -124,21 +124,23 @@ def emulate_workgroup(x, u, bias, wg_m, wg_n, TM=1):
 
 def main():
     r = np.random.default_rng(1)
-    B, H, W, Cin, Cout = 1, 7, 10, 32, 96
+    B, H, W, Cin, Cout = 1, 7, 10, 32, 192
     x = r.standard_normal((B, H, W, Cin)).astype(f32)
     w = (r.standard_normal((Cout, 3, 3, Cin)) * 0.1).astype(f32)
     bias = r.standard_normal(Cout).astype(f32)
     u = wg.transform_filters(w)
     ref = wg.conv_reference(x, u, bias)
     T = B * ((H + 1) // 2) * ((W + 1) // 2)
-    for TM in (1, 2):
+    for TM, NN in ((1, 3), (2, 3), (1, 4)):
+        if Cout % (16 * NN):
+            continue
         worst, n = 0.0, 0
         for wm in range((T + 16 * TM - 1) // (16 * TM)):
-            for wn in range(Cout // 48):
-                for (b, y, xx, col), v in emulate_workgroup(x, u, bias, wm, wn, TM).items():
+            for wn in range(Cout // (16 * NN)):
+                for (b, y, xx, col), v in emulate_workgroup(x, u, bias, wm, wn, TM, NN).items():
                     worst = max(worst, float(np.abs(v - ref[b, y, xx, col:col + 4]).max()))
                     n += 4
-        print(f'TM={TM}: emulated outputs', n, 'of', ref.size, 'max |emulation - reference| =', worst)
+        print(f'TM={TM} NN={NN}: emulated outputs', n, 'of', ref.size, 'max |emulation - reference| =', worst)
         assert n == ref.size and worst < 1e-5
     print('OK')
 
