@@ -65,6 +65,7 @@ for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: con
     TILES[_k + '+direct'] = _v | 0x2000       # never take the Winograd path
     TILES[_k + '+wtm1'] = _v | 0x4000         # Winograd: 16 tiles per workgroup
     TILES[_k + '+wtm2'] = _v | 0x8000         # Winograd: 32 tiles per workgroup
+    TILES[_k + '+nonslab'] = _v | 0x10000     # keep the m-major XCD order for large weights
 
 #: every symbol include/shapy_hip.h declares: (restype, argtypes)
 SIGNATURES = {

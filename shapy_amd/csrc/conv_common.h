@@ -42,6 +42,7 @@ struct ConvK {
   const void *wgt2;             // Winograd-transformed filters [16][Cin/16][Cout][16] f32, or null
   unsigned wgt2_bytes;
   int wino_tiles;               // B * ceil(H/2) * ceil(W/2)
+  int no_nslab;                 // tuning: keep the m-major XCD order for large weights
 };
 
 // Winograd F(2x2,3x3) path of the float32 3x3 / stride-1 layers (conv_wino.hip)
@@ -57,6 +58,15 @@ int conv2d_x6(const ConvK &k, int tile, hipStream_t s);
 // same L2.  Speed only; correctness does not depend on the placement.
 __device__ __forceinline__ int conv_tile_index(const ConvK &p) {
   int wg = blockIdx.x;
+  if (p.swz == 2) {
+    // N-slab per XCD (layers whose weights exceed an XCD's 4 MB L2, e.g. the head's 2048-wide
+    // 1x1 convs: 16.8 MB): XCD x owns the n tiles [x nbx/8, (x+1) nbx/8) for ALL m tiles, walked
+    // m-major with its own n tiles fastest.  Its weight slab stays L2-resident and every A tile
+    // is fetched once per XCD, instead of the whole weight matrix once per group of m tiles
+    // (PMC: 1.47 GB of L2 misses per 2048 -> 2048 launch with the m-major order).
+    const int npx = p.nbx >> 3, xcd = wg & 7, i = wg >> 3;
+    return (i / npx) * p.nbx + xcd * npx + i % npx;
+  }
   if (p.swz) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);

@@ -192,6 +192,8 @@ template <typename T, int BM, int BN, int WM, int WN, int UPS = 1, int KQ = 4>
 static int launch(ConvK k, hipStream_t s) {
   k.nbx = (k.Cout + BN - 1) / BN;
   k.nby = (k.M + BM - 1) / BM;
+  // weights larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
+  if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
   hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, UPS, KQ>), dim3(k.nbx * k.nby), dim3(256),
                      0, s, k);
   return (int)hipGetLastError();
@@ -283,6 +285,8 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   // HighResolutionNet.conv_algo); tile flag 0x2000 forces the direct kernel, 0x4000 / 0x8000
   // one / two tile groups per Winograd workgroup (A/B benches)
   k.wgt2 = d.wgt_wino; k.wgt2_bytes = 0; k.wino_tiles = 0;
+  k.swz = (d.tile & 0x400) ? 0 : 1;
+  k.no_nslab = (d.tile & 0x10000) ? 1 : 0;
   if (d.dtype == SHAPY_DTYPE_F32 && !(d.tile & 0x2000) && conv_wino_eligible(k))
     return conv2d_wino(k, (d.tile & 0x4000) ? 1 : (d.tile & 0x8000) ? 2 : 0, s);
   // d.tile: low byte = SHAPY_TILE_* (0 = auto).  Tuning knobs of tools/conv_bench.py:
@@ -290,7 +294,6 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   // 128-byte rows) / short (4 slots) K chunk.  Defaults (profiles/conv_bench_r01*.txt):
   // XCD-contiguous always (+2..7 %), long chunks whenever the K loop stays pipelined
   // (K >= 512 elements per slot-width: +6..20 % on the 14x14 / 7x7 layers, slower on K = 64).
-  k.swz = (d.tile & 0x400) ? 0 : 1;
   const int Kc = k.ks * k.ks * k.Cin;
   int kq = (Kc >= 128 * eps && k.Cin % (8 * eps) == 0) ? 8 : 4;
   if ((d.tile & 0x200) && k.Cin % (8 * eps) == 0) kq = 8;

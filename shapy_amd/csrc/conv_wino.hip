@@ -282,6 +282,8 @@ int conv2d_wino(ConvK k, int tm, hipStream_t s) {
   if (tm == 0) tm = (k.Cin >= 96 && (long)((k.wino_tiles + 31) / 32) * k.nbx >= 384) ? 2 : 1;
   if (nn == 4) tm = 1;                                 // 64 accumulator + 64 B-fragment registers
   k.nby = (k.wino_tiles + 16 * tm - 1) / (16 * tm);
+  // transformed filters larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
+  if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt2_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
   if (nn == 4)
     hipLaunchKernelGGL((conv_wino_kernel<4, 1>), dim3(k.nbx * k.nby), dim3(256), 0, s, k);
   else if (tm == 2)

@@ -132,6 +132,19 @@ __device__ __forceinline__ void measure_candidate(const Tri &t, float h, int f, 
   points[list * CAP + slot] = pt;
 }
 
+// Phase timing of one workgroup (tuning builds only: SHAPY_HIPCC_FLAGS=-DSHAPY_MEASURE_TIMING,
+// read back with shapy_debug_measure_times): wall_clock64 ticks at 100 MHz.
+#ifdef SHAPY_MEASURE_TIMING
+__device__ unsigned long long g_measure_times[32];
+#define M2_STAMP(slot)                                                              \
+  do {                                                                              \
+    if (blockIdx.x == 0 && blockIdx.y == 7 && threadIdx.x == 0)                     \
+      g_measure_times[slot] = wall_clock64();                                       \
+  } while (0)
+#else
+#define M2_STAMP(slot) do {} while (0)
+#endif
+
 constexpr int M2_THREADS = 1024;            // 16 waves: one workgroup owns a CU's LDS
 constexpr int M2_QCAP = 4096;               // candidate queue entries (face * 4 + plane)
 constexpr int M2_MAX_SLICES = 16;
@@ -160,6 +173,7 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
   __shared__ double red[M2_THREADS / 64];
   const int b = blockIdx.y, tid = threadIdx.x;
   const float *vb = v_shaped + (long)b * V * 3;
+  M2_STAMP(0);
   int shift = 0;
   // dbg (SHAPY_MEASURE_DBG, tuning only): 1 = no scan loop, 2 = no candidate evaluation,
   // 4 = no staging copy -- wrong results on purpose, to time the phases
@@ -194,6 +208,7 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
   }
   if (tid == 0) qn = 0;
   __syncthreads();
+  M2_STAMP(1);
   auto vtx = [&](int idx, int c) -> float {
     if constexpr (STAGED) return sv[shift + idx * 3 + c];
     else return vb[(long)idx * 3 + c];
@@ -254,6 +269,7 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
     f = fn; i0 = n0; i1 = n1; i2 = n2;
   }
   if (dropped && overflow) atomicAdd(overflow, dropped);
+  M2_STAMP(2);
   __syncthreads();
   {
     const int n = (dbg & 2) ? 0 : (qn < M2_QCAP ? qn : M2_QCAP);
@@ -262,6 +278,8 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
       process(c >> 2, c & 3, p & 1, load_face(c >> 2));
     }
   }
+  __syncthreads();
+  M2_STAMP(3);
   // deterministic reduction of the signed volume (fixed lane / wave order)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) vol += __shfl_xor(vol, o, 64);
@@ -271,6 +289,7 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
     double sum = 0.0;
     for (int w = 0; w < M2_THREADS / 64; ++w) sum += red[w];
     vol_partial[(long)b * gridDim.x + blockIdx.x] = (float)sum;
+    M2_STAMP(4);
   }
 }
 
@@ -356,6 +375,7 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
   int *stk = reinterpret_cast<int *>(hl + 3 * NP);             // 2 chains x (NP + 1) indices
   const int pl = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const long list0 = ((long)b * 3 + pl) * 2;
+  M2_STAMP(8);
   const int c0 = counters[list0], c1 = counters[list0 + 1];
   const int m0 = min(c0, CAP), m1 = min(c1, CAP);              // stored
   const int n0 = min(c0, MC), n1 = min(c1, MC);                // kept
@@ -383,6 +403,7 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
     }
   }
   __syncthreads();
+  M2_STAMP(9);
   // sort by (x, z, y): invalid (+inf) entries sink to the end
   if (npow <= 256 && NP >= 256) {
     hull_sort_in_registers<4>(px, py, pz, lane);
@@ -410,6 +431,7 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
         __syncthreads();
       }
   }
+  M2_STAMP(10);
   // compact: valid entries that differ from their predecessor (in place: the destination of
   // chunk c lies at or below its source and every earlier chunk has been consumed)
   int n = 0;
@@ -427,6 +449,7 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
     n += __popcll(mask);
     __syncthreads();
   }
+  M2_STAMP(11);
   // monotone chains: lane 0 walks left -> right (lower hull), lane 1 right -> left (upper hull)
   int *st = stk + (lane & 1) * (NP + 1);
   int m = 0;
@@ -446,6 +469,7 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
     }
   }
   __syncthreads();
+  M2_STAMP(12);
   const int ml = __shfl(m, 0, 64), mu = __shfl(m, 1, 64);
   // perimeter: lower edges then upper edges, one edge per lane and round
   float perim = 0.f;
@@ -463,6 +487,7 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
     }
     perim += wave_reduce_sum(len);
   }
+  M2_STAMP(13);
   if (lane == 0) {
     out[b * 5 + 2 + pl] = perim;
     if (pl == 0) {
@@ -474,6 +499,7 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
       const float head = lm_coord(vtx, faces, lm, 0, 1), heel = lm_coord(vtx, faces, lm, 1, 1);
       out[b * 5 + 1] = fabsf(head - heel);                  // compute_height (:182-199)
     }
+    if (lane == 0) M2_STAMP(14);
   }
 }
 
@@ -590,3 +616,10 @@ extern "C" int shapy_body_measure_f32(const float *v_shaped, const int32_t *face
                      max_coll, CAP, NP, S, lm, counters, vol, pts, out, overflow_out);
   return (int)hipGetLastError();
 }
+
+#ifdef SHAPY_MEASURE_TIMING
+extern "C" int shapy_debug_measure_times(unsigned long long *out_host) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(shapy::g_measure_times),
+                                  sizeof(unsigned long long) * 32);
+}
+#endif
