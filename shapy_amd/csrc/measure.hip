@@ -109,18 +109,29 @@ __device__ __forceinline__ float lm_coord(VF vtx, const int32_t *faces, const La
   return (a * lm.bc[which][0] + b * lm.bc[which][1]) + c * lm.bc[which][2];
 }
 
-// SAT + first-hit point of one (face, plane, plane triangle) candidate of the fused scan
-__device__ __forceinline__ void measure_candidate(const Tri &t, float h, int f, long list, int qi,
-                                                  int CAP, int *__restrict__ counters,
-                                                  float4 *__restrict__ points) {
+// Candidates of the fused scan: SAT, then first-hit point of (face, plane, plane triangle QI).
+// QI is a template parameter: the plane triangle's vertices are then compile-time constants
+// (+-1 and the height h), which lets the compiler fold part of the 11 axis tests.
+template <int QI>
+__device__ __forceinline__ Tri plane_triangle(float h) {
   // _get_plane_at_heights (body_measurements.py:86-97): quad (c0,c1,c2,c3) as 2 triangles
   Tri q;
   q.v0 = v3(-1.f, h, -1.f);
-  q.v1 = qi == 0 ? v3(1.f, h, -1.f) : v3(1.f, h, 1.f);
-  q.v2 = qi == 0 ? v3(1.f, h, 1.f) : v3(-1.f, h, 1.f);
-  if (!(aabb_overlap(q, t) && tri_tri_sat(q, t))) return;
-  const int slot = atomicAdd(counters + list, 1);
-  if (slot >= CAP) return;
+  q.v1 = QI == 0 ? v3(1.f, h, -1.f) : v3(1.f, h, 1.f);
+  q.v2 = QI == 0 ? v3(1.f, h, 1.f) : v3(-1.f, h, 1.f);
+  return q;
+}
+
+template <int QI>
+__device__ __forceinline__ bool candidate_hit(const Tri &t, float h) {
+  const Tri q = plane_triangle<QI>(h);
+  return aabb_overlap(q, t) && tri_tri_sat(q, t);
+}
+
+template <int QI>
+__device__ __forceinline__ void candidate_point(const Tri &t, float h, int f,
+                                                float4 *__restrict__ dst) {
+  const Tri q = plane_triangle<QI>(h);
   V3 bc = v3(0.f, 0.f, 0.f);
   tri_tri_point(q, t, bc);
   // points = sum_k bc_k * tri_k (body_measurements.py:144-147)
@@ -129,7 +140,7 @@ __device__ __forceinline__ void measure_candidate(const Tri &t, float h, int f, 
   pt.y = (t.v0.y * bc.x + t.v1.y * bc.y) + t.v2.y * bc.z;
   pt.z = (t.v0.z * bc.x + t.v1.z * bc.y) + t.v2.z * bc.z;
   pt.w = __int_as_float(f);
-  points[list * CAP + slot] = pt;
+  *dst = pt;
 }
 
 // Phase timing of one workgroup (tuning builds only: SHAPY_HIPCC_FLAGS=-DSHAPY_MEASURE_TIMING,
@@ -169,6 +180,7 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
   extern __shared__ __attribute__((aligned(16))) float sv[];
   __shared__ int queue[M2_QCAP];
   __shared__ int qn;
+  __shared__ int lcnt[6];            // hits per (plane, plane triangle) when the mesh is not sliced
   __shared__ float hs[3];
   __shared__ double red[M2_THREADS / 64];
   const int b = blockIdx.y, tid = threadIdx.x;
@@ -207,6 +219,7 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
     for (int i = head + n4 * 4 + tid; i < N; i += M2_THREADS) sv[shift + i] = vb[i];
   }
   if (tid == 0) qn = 0;
+  if (tid < 6) lcnt[tid] = 0;
   __syncthreads();
   M2_STAMP(1);
   auto vtx = [&](int idx, int c) -> float {
@@ -222,9 +235,6 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
     t.v1 = v3(vtx(i1, 0), vtx(i1, 1), vtx(i1, 2));
     t.v2 = v3(vtx(i2, 0), vtx(i2, 1), vtx(i2, 2));
     return t;
-  };
-  auto process = [&](int f, int pl, int qi, const Tri &t) {
-    measure_candidate(t, hs[pl], f, ((long)b * 3 + pl) * 2 + qi, qi, CAP, counters, points);
   };
   // The scan runs without barriers (every wave streams its faces at its own pace; the face
   // indices of the next iteration are in flight while this one is evaluated).  Candidates
@@ -272,14 +282,29 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
   M2_STAMP(2);
   __syncthreads();
   {
+    // candidate evaluation: pairs [0, n) test plane triangle 0, [n, 2n) plane triangle 1 (a
+    // wave runs ONE specialisation).  Two passes over the SAT would double the cost, so the
+    // slot comes from an atomic AFTER the SAT: LDS counters when the mesh belongs to this
+    // workgroup alone, global ones when it is sliced.
     const int n = (dbg & 2) ? 0 : (qn < M2_QCAP ? qn : M2_QCAP);
-    for (int p = tid; p < 2 * n; p += M2_THREADS) {
-      const int c = queue[p >> 1];
-      process(c >> 2, c & 3, p & 1, load_face(c >> 2));
+    for (int p0 = 0; p0 < 2 * n; p0 += M2_THREADS) {
+      const int p = p0 + tid;
+      if (p >= 2 * n) continue;
+      const int qi = p >= n, c = queue[qi ? p - n : p], f = c >> 2, pl = c & 3;
+      const Tri t = load_face(f);
+      const long list = ((long)b * 3 + pl) * 2 + qi;
+      const float h = hs[pl];
+      if (!(qi == 0 ? candidate_hit<0>(t, h) : candidate_hit<1>(t, h))) continue;
+      const int slot = gridDim.x == 1 ? atomicAdd(&lcnt[pl * 2 + qi], 1)
+                                      : atomicAdd(counters + list, 1);
+      if (slot >= CAP) continue;
+      if (qi == 0) candidate_point<0>(t, h, f, points + list * CAP + slot);
+      else candidate_point<1>(t, h, f, points + list * CAP + slot);
     }
   }
   __syncthreads();
   M2_STAMP(3);
+  if (gridDim.x == 1 && tid < 6) counters[(long)b * 6 + tid] = lcnt[tid];
   // deterministic reduction of the signed volume (fixed lane / wave order)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) vol += __shfl_xor(vol, o, 64);
@@ -293,75 +318,24 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
   }
 }
 
-// Bitonic sort of 64 * E points held in registers, element e = lane * E + r, ascending by
-// (x, z, y).  Compare-exchange distances below E stay inside a lane (register swaps); the others
-// exchange whole points with lane ^ (j / E) through __shfl_xor.  512 points: 24 in-register and
-// 21 cross-lane steps -- no LDS round trips and no barriers (the LDS version of the same
-// network spent ~45 us per hull on them).
-template <int E>
-__device__ __forceinline__ void wave_bitonic_sort(float (&x)[E], float (&z)[E], float (&y)[E],
-                                                  int lane) {
-  constexpr int N = 64 * E;
-  // stages (k) and cross-lane steps (j >= E) are run-time loops -- a fully unrolled network
-  // (45 steps x E points) spilled hundreds of registers; the in-register steps (j < E) index
-  // the point arrays with compile-time constants
-#pragma unroll 1
-  for (int k = 2; k <= N; k <<= 1) {
-#pragma unroll 1
-    for (int j = k >> 1; j >= E; j >>= 1) {
-      const int lm = j / E;
-      const bool lower = (lane & lm) == 0;
-      const bool up = ((lane * E) & k) == 0;        // k >= 2 E here: the same for all r
-#pragma unroll
-      for (int r = 0; r < E; ++r) {
-        const float ox = __shfl_xor(x[r], lm, 64), oz = __shfl_xor(z[r], lm, 64),
-                    oy = __shfl_xor(y[r], lm, 64);
-        const bool o_lt = ox < x[r] || (ox == x[r] && (oz < z[r] || (oz == z[r] && oy < y[r])));
-        const bool m_lt = x[r] < ox || (x[r] == ox && (z[r] < oz || (z[r] == oz && y[r] < oy)));
-        // the lower index of a pair keeps the smaller point in an ascending block
-        if ((lower == up) ? o_lt : m_lt) { x[r] = ox; z[r] = oz; y[r] = oy; }
-      }
-    }
-#pragma unroll
-    for (int j = E / 2; j > 0; j >>= 1) {
-      if (j < k) {
-#pragma unroll
-        for (int r = 0; r < E; ++r) {
-          if ((r & j) == 0) {
-            const int q = r | j;
-            const bool up = ((lane * E + r) & k) == 0;
-            const bool gt = x[r] > x[q] || (x[r] == x[q] && (z[r] > z[q] || (z[r] == z[q] && y[r] > y[q])));
-            if (gt == up) {
-              const float tx = x[r], tz = z[r], ty = y[r];
-              x[r] = x[q]; z[r] = z[q]; y[r] = y[q];
-              x[q] = tx; z[q] = tz; y[q] = ty;
-            }
-          }
-        }
-      }
-    }
-  }
-}
-
-template <int E>
-__device__ __forceinline__ void hull_sort_in_registers(float *px, float *py, float *pz, int lane) {
-  float x[E], z[E], y[E];
-#pragma unroll
-  for (int r = 0; r < E; ++r) { x[r] = px[lane * E + r]; z[r] = pz[lane * E + r]; y[r] = py[lane * E + r]; }
-  wave_bitonic_sort<E>(x, z, y, lane);
-#pragma unroll
-  for (int r = 0; r < E; ++r) { px[lane * E + r] = x[r]; pz[lane * E + r] = z[r]; py[lane * E + r] = y[r]; }
-}
-
-// One wave per (mesh, plane): gather the <= 2 * MC points of the two plane triangles, bitonic
-// sort by (x, z, y) in LDS (the result is a pure function of the point SET: the atomic order of
-// the scan does not matter), drop exact duplicates (every mesh edge that crosses the plane is
-// reported by both triangles sharing it), then Andrew's monotone chain in the (x, z) plane with
-// float64 orientation tests -- the lower chain on lane 0 and the upper chain on lane 1 at the
-// same time, the two topmost stack points held in registers so that a step without a pop needs
-// no LDS round trip -- and the 3-D perimeter (body_measurements.py:160-179) as a wave
-// reduction over the hull edges.  One wave instead of one workgroup per hull: the chain is
-// serial either way, and the 3,000 waves of 1,000 meshes are all resident at once.
+// One wave per (mesh, plane).  Everything after the gather is data-parallel over the lanes:
+//   1. gather the <= 2 * MC points of the two plane triangles into LDS;
+//   2. rank sort by (x, z, y, slot): every lane counts, for each of its points, the points that
+//      precede it (n broadcast LDS reads per point) and scatters it to its rank -- the result is
+//      a pure function of the point SET (the atomic order of the scan does not matter).  ~5 us
+//      for the ~160 points of a body cross-section; a bitonic network through LDS or through
+//      wave shuffles took 25-45 us (one dependent round trip per compare-exchange);
+//   3. drop exact duplicates (every mesh edge that crosses the plane is reported by both
+//      triangles sharing it) by ballot compaction;
+//   4. lower and upper hull by ELIMINATION ROUNDS instead of a serial monotone chain (0.55 us per
+//      point on one lane: 44 us): every interior point of the x-sorted chain whose turn
+//      orient(prev, p, next) has the wrong sign (float64 test, collinear counts as wrong) lies
+//      on or inside the segment of two other points of the set, so all of them can be dropped at
+//      once; survivors are compacted and tested again until a round removes nothing.  Near-convex
+//      cross-sections finish in 2-4 rounds; the fixed point is exactly the strictly convex
+//      chain Andrew's scan returns;
+//   5. the 3-D perimeter (body_measurements.py:160-179) as a wave reduction over the edges of
+//      both chains.
 // Overflow (more than MC hits of one plane triangle): the MC LOWEST face indices are kept, the
 // rule of the ascending-order CPU oracle -- deterministic as long as the scan could store all
 // hits (CAP >= 256 slots per list); the excess is counted in *overflow either way.
@@ -372,7 +346,8 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
     float *__restrict__ out, int *__restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) float hl[];
   float *px = hl, *py = hl + NP, *pz = hl + 2 * NP;
-  int *stk = reinterpret_cast<int *>(hl + 3 * NP);             // 2 chains x (NP + 1) indices
+  // chain index lists: [chain (lower, upper)][ping-pong][NP] as 16-bit indices
+  unsigned short *chain = reinterpret_cast<unsigned short *>(hl + 3 * NP);
   const int pl = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const long list0 = ((long)b * 3 + pl) * 2;
   M2_STAMP(8);
@@ -380,8 +355,7 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
   const int m0 = min(c0, CAP), m1 = min(c1, CAP);              // stored
   const int n0 = min(c0, MC), n1 = min(c1, MC);                // kept
   if (lane == 0 && overflow && (c0 > MC || c1 > MC)) atomicAdd(overflow, (c0 - n0) + (c1 - n1));
-  int npow = 2;
-  while (npow < n0 + n1) npow <<= 1;
+  const int nn = n0 + n1;
   for (int i = lane; i < NP; i += 64) { px[i] = INFINITY; py[i] = 0.f; pz[i] = INFINITY; }
   __syncthreads();
 #pragma unroll
@@ -404,41 +378,46 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
   }
   __syncthreads();
   M2_STAMP(9);
-  // sort by (x, z, y): invalid (+inf) entries sink to the end
-  if (npow <= 256 && NP >= 256) {
-    hull_sort_in_registers<4>(px, py, pz, lane);
-    npow = 256;
-    __syncthreads();
-  } else if (npow <= 512 && NP >= 512) {
-    hull_sort_in_registers<8>(px, py, pz, lane);
-    npow = 512;
-    __syncthreads();
-  } else {                                  // max_collisions > 256: the same network through LDS
-    for (int k = 2; k <= npow; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = lane; i < npow; i += 64) {
-          const int l = i ^ j;
-          if (l > i) {
-            const bool up = (i & k) == 0;
-            const float ax = px[i], az = pz[i], ay = py[i], bx = px[l], bz = pz[l], by = py[l];
-            const bool gt = ax > bx || (ax == bx && (az > bz || (az == bz && ay > by)));
-            if (gt == up) {
-              px[i] = bx; pz[i] = bz; py[i] = by;
-              px[l] = ax; pz[l] = az; py[l] = ay;
-            }
-          }
+  // ---- rank sort of the slots [0, nn): (x, z, y), ties by slot; +inf holes sink to the end ----
+  constexpr int EPL = 16;                              // slots per lane (NP <= 1024)
+  {
+    float ex[EPL], ey[EPL], ez[EPL];
+    int rank[EPL];
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+      const int e = lane + 64 * r;
+      ex[r] = e < nn ? px[e] : INFINITY; ey[r] = e < nn ? py[e] : 0.f; ez[r] = e < nn ? pz[e] : INFINITY;
+      rank[r] = 0;
+    }
+    const int per = (nn + 63) >> 6;                    // slots this wave actually uses per lane
+    for (int j = 0; j < nn; ++j) {
+      const float jx = px[j], jy = py[j], jz = pz[j];  // broadcast reads
+#pragma unroll
+      for (int r = 0; r < EPL; ++r) {
+        if (r < per) {
+          const int e = lane + 64 * r;
+          const bool lt = jx < ex[r] || (jx == ex[r] && (jz < ez[r] || (jz == ez[r] && (jy < ey[r] ||
+                          (jy == ey[r] && j < e)))));
+          rank[r] += lt;
         }
-        __syncthreads();
       }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+      const int e = lane + 64 * r;
+      if (r < per && e < nn) { px[rank[r]] = ex[r]; py[rank[r]] = ey[r]; pz[rank[r]] = ez[r]; }
+    }
+    __syncthreads();
   }
   M2_STAMP(10);
-  // compact: valid entries that differ from their predecessor (in place: the destination of
-  // chunk c lies at or below its source and every earlier chunk has been consumed)
+  // ---- compact: valid entries that differ from their predecessor (in place: the destination
+  // of chunk c lies at or below its source and every earlier chunk has been consumed) ----
   int n = 0;
-  for (int i0 = 0; i0 < npow; i0 += 64) {
+  for (int i0 = 0; i0 < nn; i0 += 64) {
     const int i = i0 + lane;
     const float x = px[i], y = py[i], z = pz[i];
-    bool keep = i < npow && x != INFINITY;
+    bool keep = i < nn && x != INFINITY;
     if (keep && i > 0) keep = !(px[i - 1] == x && py[i - 1] == y && pz[i - 1] == z);
     const unsigned long long mask = __ballot(keep);
     __syncthreads();
@@ -450,42 +429,64 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
     __syncthreads();
   }
   M2_STAMP(11);
-  // monotone chains: lane 0 walks left -> right (lower hull), lane 1 right -> left (upper hull)
-  int *st = stk + (lane & 1) * (NP + 1);
-  int m = 0;
-  if (lane < 2 && n >= 1) {
-    const int step = lane == 0 ? 1 : -1;
-    int i = lane == 0 ? 0 : n - 1;
-    double ox = 0, oz = 0, ax = 0, az = 0;          // stack[m-2], stack[m-1]
-    for (int it = 0; it < n; ++it, i += step) {
-      const double cx = (double)px[i], cz = (double)pz[i];
-      while (m >= 2 && (ax - ox) * (cz - oz) - (az - oz) * (cx - ox) <= 0.0) {
-        --m;
-        ax = ox; az = oz;
-        if (m >= 2) { const int q = st[m - 2]; ox = (double)px[q]; oz = (double)pz[q]; }
-      }
-      st[m++] = i;
-      ox = ax; oz = az; ax = cx; az = cz;
-    }
+  // ---- lower / upper chain by elimination rounds ----
+  int len[2] = {n, n};                                 // current chain lengths (wave-uniform)
+  for (int i = lane; i < n; i += 64) {
+    chain[0 * 2 * NP + i] = (unsigned short)i;         // lower, buffer 0
+    chain[1 * 2 * NP + i] = (unsigned short)i;         // upper, buffer 0
   }
   __syncthreads();
+  int cur = 0;
+  for (int round = 0; round < 2 * NP; ++round) {
+    bool changed = false;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const unsigned short *src = chain + c * 2 * NP + cur * NP;
+      unsigned short *dst = chain + c * 2 * NP + (cur ^ 1) * NP;
+      const int m = len[c];
+      int kept = 0;
+      for (int k0 = 0; k0 < m; k0 += 64) {
+        const int k = k0 + lane;
+        bool keep = k < m;
+        unsigned short a = 0;
+        if (keep) {
+          a = src[k];
+          if (k > 0 && k < m - 1) {
+            const int o = src[k - 1], q = src[k + 1];
+            const double ox = px[o], oz = pz[o];
+            const double t = ((double)px[a] - ox) * ((double)pz[q] - oz) -
+                             ((double)pz[a] - oz) * ((double)px[q] - ox);
+            keep = c == 0 ? t > 0.0 : t < 0.0;         // left turns below, right turns above
+          }
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (keep) dst[kept + __popcll(mask & ((1ull << lane) - 1ull))] = a;
+        kept += __popcll(mask);
+      }
+      changed |= kept != m;
+      len[c] = kept;
+    }
+    __syncthreads();
+    cur ^= 1;
+    if (!changed) break;
+  }
   M2_STAMP(12);
-  const int ml = __shfl(m, 0, 64), mu = __shfl(m, 1, 64);
-  // perimeter: lower edges then upper edges, one edge per lane and round
+  // ---- perimeter: the edges of both chains, one edge per lane and round ----
   float perim = 0.f;
+  const int ml = len[0], mu = len[1];
   const int ne = (ml > 0 ? ml - 1 : 0) + (mu > 0 ? mu - 1 : 0);
   for (int e0 = 0; e0 < ne; e0 += 64) {
     const int e = e0 + lane;
-    float len = 0.f;
+    float elen = 0.f;
     if (e < ne) {
       const bool lower = e < ml - 1;
-      const int *s2 = stk + (lower ? 0 : NP + 1);
+      const unsigned short *s2 = chain + (lower ? 0 : 2 * NP) + cur * NP;
       const int k = lower ? e : e - (ml - 1);
       const int a = s2[k], c = s2[k + 1];
       const float dx = px[c] - px[a], dy = py[c] - py[a], dz = pz[c] - pz[a];
-      len = sqrtf(dx * dx + dy * dy + dz * dz);
+      elen = sqrtf(dx * dx + dy * dy + dz * dz);
     }
-    perim += wave_reduce_sum(len);
+    perim += wave_reduce_sum(elen);
   }
   M2_STAMP(13);
   if (lane == 0) {
@@ -611,7 +612,7 @@ extern "C" int shapy_body_measure_f32(const float *v_shaped, const int32_t *face
   SHAPY_HIP_TRY(hipGetLastError());
   int NP = 64;                              // >= one wave's worth: the compaction reads whole chunks
   while (NP < 2 * max_coll) NP <<= 1;
-  const size_t hull_lds = (size_t)(5 * NP + 2) * 4;
+  const size_t hull_lds = (size_t)(3 * NP) * 4 + (size_t)(4 * NP) * 2;   // points + 2 x 2 index lists
   hipLaunchKernelGGL(measure_hull2_kernel, dim3(3, B), dim3(64), hull_lds, s, v_shaped, faces, V,
                      max_coll, CAP, NP, S, lm, counters, vol, pts, out, overflow_out);
   return (int)hipGetLastError();
