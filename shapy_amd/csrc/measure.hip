@@ -320,13 +320,14 @@ __global__ __launch_bounds__(M2_THREADS) void measure_scan2_kernel(
 
 // One wave per (mesh, plane).  Everything after the gather is data-parallel over the lanes:
 //   1. gather the <= 2 * MC points of the two plane triangles into LDS;
-//   2. rank sort by (x, z, y, slot): every lane counts, for each of its points, the points that
+//   2. rank sort by (x, z, slot): every lane counts, for each of its points, the points that
 //      precede it (n broadcast LDS reads per point) and scatters it to its rank -- the result is
 //      a pure function of the point SET (the atomic order of the scan does not matter).  ~5 us
 //      for the ~160 points of a body cross-section; a bitonic network through LDS or through
 //      wave shuffles took 25-45 us (one dependent round trip per compare-exchange);
-//   3. drop exact duplicates (every mesh edge that crosses the plane is reported by both
-//      triangles sharing it) by ballot compaction;
+//   3. drop duplicates in (x, z) (every mesh edge that crosses the plane is reported by both
+//      triangles sharing it, sometimes one ulp apart in y) by ballot compaction -- coincident
+//      points would justify each other's removal in step 4;
 //   4. lower and upper hull by ELIMINATION ROUNDS instead of a serial monotone chain (0.55 us per
 //      point on one lane: 44 us): every interior point of the x-sorted chain whose turn
 //      orient(prev, p, next) has the wrong sign (float64 test, collinear counts as wrong) lies
@@ -378,27 +379,41 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
   }
   __syncthreads();
   M2_STAMP(9);
-  // ---- rank sort of the slots [0, nn): (x, z, y), ties by slot; +inf holes sink to the end ----
+  // ---- rank sort of the slots [0, nn) by (x, z), ties by slot; +inf holes sink to the end ----
+  // one order-preserving 64-bit key per point (parked in the chain buffers, which are not
+  // needed yet): a comparison is two integer compares instead of a lexicographic float cascade
   constexpr int EPL = 16;                              // slots per lane (NP <= 1024)
   {
+    unsigned long long *key = reinterpret_cast<unsigned long long *>(chain);
+    auto ord = [](float f) -> unsigned {
+      const unsigned u = __float_as_uint(f);
+      return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+    };
+    for (int i = lane; i < nn + 4; i += 64)
+      key[i] = i < nn ? ((unsigned long long)ord(px[i]) << 32) | ord(pz[i]) : ~0ull;
+    __syncthreads();
+    const int per = (nn + 63) >> 6;                    // slots this wave actually uses per lane
     float ex[EPL], ey[EPL], ez[EPL];
+    unsigned long long ke[EPL];
     int rank[EPL];
 #pragma unroll
     for (int r = 0; r < EPL; ++r) {
       const int e = lane + 64 * r;
-      ex[r] = e < nn ? px[e] : INFINITY; ey[r] = e < nn ? py[e] : 0.f; ez[r] = e < nn ? pz[e] : INFINITY;
+      const bool in = r < per && e < nn;
+      ex[r] = in ? px[e] : INFINITY; ey[r] = in ? py[e] : 0.f; ez[r] = in ? pz[e] : INFINITY;
+      ke[r] = in ? key[e] : ~0ull;
       rank[r] = 0;
     }
-    const int per = (nn + 63) >> 6;                    // slots this wave actually uses per lane
-    for (int j = 0; j < nn; ++j) {
-      const float jx = px[j], jy = py[j], jz = pz[j];  // broadcast reads
+    for (int j = 0; j < nn; j += 4) {
+      const unsigned long long k0 = key[j], k1 = key[j + 1], k2 = key[j + 2], k3 = key[j + 3];
 #pragma unroll
       for (int r = 0; r < EPL; ++r) {
         if (r < per) {
           const int e = lane + 64 * r;
-          const bool lt = jx < ex[r] || (jx == ex[r] && (jz < ez[r] || (jz == ez[r] && (jy < ey[r] ||
-                          (jy == ey[r] && j < e)))));
-          rank[r] += lt;
+          rank[r] += (int)(k0 < ke[r] || (k0 == ke[r] && j < e)) +
+                     (int)(k1 < ke[r] || (k1 == ke[r] && j + 1 < e)) +
+                     (int)(k2 < ke[r] || (k2 == ke[r] && j + 2 < e)) +
+                     (int)(k3 < ke[r] || (k3 == ke[r] && j + 3 < e));
         }
       }
     }
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
     const int i = i0 + lane;
     const float x = px[i], y = py[i], z = pz[i];
     bool keep = i < nn && x != INFINITY;
-    if (keep && i > 0) keep = !(px[i - 1] == x && py[i - 1] == y && pz[i - 1] == z);
+    if (keep && i > 0) keep = !(px[i - 1] == x && pz[i - 1] == z);
     const unsigned long long mask = __ballot(keep);
     __syncthreads();
     if (keep) {
@@ -612,7 +627,7 @@ extern "C" int shapy_body_measure_f32(const float *v_shaped, const int32_t *face
   SHAPY_HIP_TRY(hipGetLastError());
   int NP = 64;                              // >= one wave's worth: the compaction reads whole chunks
   while (NP < 2 * max_coll) NP <<= 1;
-  const size_t hull_lds = (size_t)(3 * NP) * 4 + (size_t)(4 * NP) * 2;   // points + 2 x 2 index lists
+  const size_t hull_lds = (size_t)(3 * NP) * 4 + (size_t)(4 * NP) * 2 + 64;   // points + 2 x 2 index lists (+ key pad)
   hipLaunchKernelGGL(measure_hull2_kernel, dim3(3, B), dim3(64), hull_lds, s, v_shaped, faces, V,
                      max_coll, CAP, NP, S, lm, counters, vol, pts, out, overflow_out);
   return (int)hipGetLastError();
