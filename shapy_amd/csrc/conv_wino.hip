@@ -39,6 +39,18 @@ __device__ __forceinline__ float quad_partner(float x) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x5A, 0xf, 0xf, true));
 }
 
+// Phase timing of one workgroup (tuning builds only: -DSHAPY_WINO_TIMING, read back with
+// shapy_debug_wino_times; wall_clock64 ticks at 100 MHz)
+#ifdef SHAPY_WINO_TIMING
+__device__ unsigned long long g_wino_times[16];
+#define WINO_STAMP(slot)                                                            \
+  do {                                                                              \
+    if (blockIdx.x == gridDim.x / 2 + 1 && threadIdx.x == 0) g_wino_times[slot] = wall_clock64(); \
+  } while (0)
+#else
+#define WINO_STAMP(slot) do {} while (0)
+#endif
+
 template <int NN, int TM>
 __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino_kernel(ConvK p) {
   constexpr int N = 16 * NN, NCP = N + 4, N4 = N / 4, MT = 16 * TM;
@@ -50,6 +62,7 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
   __shared__ __attribute__((aligned(16))) char lds[2 * LDS_V > LDS_X ? 2 * LDS_V : LDS_X];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  WINO_STAMP(0);
   const int wg = conv_tile_index(p);
   const int m_blk = (wg / p.nbx) * MT, n_blk = (wg % p.nbx) * N;
   const int H = p.Hi, W = p.Wi;
@@ -145,6 +158,7 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
   for (int pp = 0; pp < 4; ++pp) bload(pp, 0, true);
   lstore(0);
   __syncthreads();
+  WINO_STAMP(1);
 
   for (int cc = 0; cc < CC; ++cc) {
     const bool more = cc + 1 < CC;
@@ -170,7 +184,9 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
     // barrier below: it can be overwritten while slower waves still multiply this one
     lstore((cc + 1) & 1);                    // (zeros after the last chunk: never read)
     __syncthreads();
+    if (cc == 0) WINO_STAMP(2);
   }
+  WINO_STAMP(3);
 
   const float *res = reinterpret_cast<const float *>(p.res);
   float *out = reinterpret_cast<float *>(p.out);
@@ -221,6 +237,7 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
             M[((4 * wave + pp) * 16 + 4 * kq + rg) * NCP + n * 16 + l15] = acc[pp][mt][n][rg];
     }
     __syncthreads();
+    if (mt == 0) WINO_STAMP(4);
 
     // ---- output transform + bias + residual + ReLU + store ----
     if (active) {
@@ -255,6 +272,7 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
         }
     }
   }
+  WINO_STAMP(5);
 }
 
 bool conv_wino_eligible(const ConvK &k) {
@@ -294,3 +312,9 @@ int conv2d_wino(ConvK k, int tm, hipStream_t s) {
 }
 
 }  // namespace shapy
+
+#ifdef SHAPY_WINO_TIMING
+extern "C" int shapy_debug_wino_times(unsigned long long *out_host) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(shapy::g_wino_times), sizeof(unsigned long long) * 16);
+}
+#endif
