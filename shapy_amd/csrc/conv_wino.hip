@@ -99,15 +99,57 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
   const int st_off = tile_s * 64 + (((c4 ^ fsw ^ r) & 3) << 4) + 4 * r * PSTR;   // + j * PSTR
 
   u32x4 raw[TM][4];
-  // loads past the last chunk are issued with an out-of-range offset (they return 0 without
-  // touching memory): no branch around them, so the compiler's vmcnt counts stay exact
+  // Every chunk iteration issues the same 4 TM loads into raw[] (no branch around them, so the
+  // compiler's vmcnt counts stay exact): the next chunk's patch rows -- or, in the LAST
+  // iteration, this thread's residual pixels for the epilogue, whose HBM latency then hides
+  // behind the last chunk's MFMAs and the accumulator exchange.
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(p.res ? p.res : p.in), 0, 0x7ffffffe, 0x00020000);
+  const bool has_res = p.res != nullptr;
+  // epilogue item of this thread for tile group mt: (tile tl, channels col .. col + 3)
+  const int c4o = t % N4, tl = t / N4;
+  const int col = n_blk + c4o * 4;
+  auto item = [&](int mt, bool (&ok)[4], int (&pixi)[4]) {
+    const int tile = m_blk + 16 * mt + tl;
+    const bool active = t < 16 * N4 && tile < T && col < p.Cout;
+    const int tt_ = active ? tile : 0;
+    const int tx = tt_ % TW;
+    const int tq = tt_ / TW;
+    const int ty = tq % TH;
+    const int b = tq / TH;
+    const int oy = 2 * ty, ox = 2 * tx;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int a = k >> 1, bb = k & 1;
+      ok[k] = active && oy + a < H && ox + bb < W;
+      pixi[k] = (b * H + oy + a) * W + ox + bb;
+    }
+  };
   auto gload = [&](int c0, bool live) {
+    if (live) {
 #pragma unroll
-    for (int s = 0; s < TM; ++s)
+      for (int s = 0; s < TM; ++s)
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        raw[s][k] = __builtin_amdgcn_raw_buffer_load_b128(
-            rs_in, (live && rowok[s] && xok[s][k]) ? a_off[s] + k * pix_stride + c0 * 4 : OOB, 0, 0);
+        for (int k = 0; k < 4; ++k)
+          raw[s][k] = __builtin_amdgcn_raw_buffer_load_b128(
+              rs_in, (rowok[s] && xok[s][k]) ? a_off[s] + k * pix_stride + c0 * 4 : OOB, 0, 0);
+    } else {
+#pragma unroll
+      for (int s = 0; s < TM; ++s) {
+        bool ok[4];
+        int pixi[4];
+        item(s, ok, pixi);
+        int off[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {       // plain selects: no divergent branch around a load
+          const int o = (pixi[k] * p.res_ld + p.res_coff + col) * 4;
+          off[k] = (has_res & ok[k]) ? o : OOB;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          raw[s][k] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off[k], 0, 0);
+      }
+    }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
@@ -182,44 +224,28 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
     }
     // the other buffer was last read in iteration cc - 1, which every wave left through the
     // barrier below: it can be overwritten while slower waves still multiply this one
-    lstore((cc + 1) & 1);                    // (zeros after the last chunk: never read)
+    if (more) lstore((cc + 1) & 1);          // (after the last chunk raw[] holds the residual)
     __syncthreads();
     if (cc == 0) WINO_STAMP(2);
   }
   WINO_STAMP(3);
 
-  const float *res = reinterpret_cast<const float *>(p.res);
   float *out = reinterpret_cast<float *>(p.out);
   static_assert(16 * N4 <= 256, "one (tile, 4 channels) epilogue item per thread");
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt) {
-    // ---- epilogue item of this thread: (tile tl, channels col .. col + 3) ----
-    const int c4o = t % N4, tl = t / N4;
-    const int tile = m_blk + 16 * mt + tl;
-    const int col = n_blk + c4o * 4;
-    const bool active = t < 16 * N4 && tile < T && col < p.Cout;
+    bool okk[4];
+    int pixi[4];
+    item(mt, okk, pixi);
+    const bool active = okk[0];              // pixel (0,0) of a live tile is always inside
     bool ok[2][2];
     long pix[2][2];
     f32x4 rv[2][2];
-    {
-      const int tt_ = active ? tile : 0;
-      const int tx = tt_ % TW;
-      const int tq = tt_ / TW;
-      const int ty = tq % TH;
-      const int b = tq / TH;
-      const int oy = 2 * ty, ox = 2 * tx;
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          ok[a][bb] = active && oy + a < H && ox + bb < W;
-          pix[a][bb] = ((long)(b * H + oy + a) * W + ox + bb);
-          // the residual is requested BEFORE the accumulators are parked: its latency hides
-          // behind the exchange (the B-fragment registers are free by now)
-          rv[a][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (res && ok[a][bb])
-            rv[a][bb] = *reinterpret_cast<const f32x4 *>(res + pix[a][bb] * p.res_ld + p.res_coff + col);
-        }
+    for (int k = 0; k < 4; ++k) {
+      ok[k >> 1][k & 1] = okk[k];
+      pix[k >> 1][k & 1] = pixi[k];
+      rv[k >> 1][k & 1] = __builtin_bit_cast(f32x4, raw[mt][k]);   // 0 where there is no residual
     }
     f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.bias && active) bias = *reinterpret_cast<const f32x4 *>(p.bias + col);
