@@ -233,7 +233,11 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
           for (int n = 0; n < NN; ++n)
             acc[pp][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                 __uint_as_float(af[m][kk]), __uint_as_float(bfr[pp][n][kk]), acc[pp][m][n], 0, 0, 0);
+      // keep the refill of this position's B fragments HERE (hipcc otherwise sinks all 12 loads
+      // to the end of the iteration, one LDS store + barrier before their first use)
+      __builtin_amdgcn_sched_barrier(0);
       bload(pp, cc + 1, more);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // the other buffer was last read in iteration cc - 1, which every wave left through the
     // barrier below: it can be overwritten while slower waves still multiply this one

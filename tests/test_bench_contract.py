@@ -8,7 +8,8 @@ import pytest
 ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
 
 
-@pytest.mark.parametrize('name', ['r01_bench_f32.json', 'r01_bench_f32x6.json', 'r01_bench_bf16.json'])
+@pytest.mark.parametrize('name', ['r01_bench_f32.json', 'r01_bench_f32x6.json', 'r01_bench_bf16.json',
+                                  'r02g_bench_f32_winograd_default.json'])
 def test_committed_bench_line_has_the_contract_fields(name):
     with open(osp.join(ROOT, 'profiles', name)) as f:
         r = json.loads(f.read().strip().splitlines()[-1])
@@ -35,3 +36,20 @@ def test_committed_bench_line_has_the_contract_fields(name):
         for k in ('value', 'unit', 'cores', 'kind', 'sample'):
             assert k in cb, k
         assert cb['kind'] in ('reference', 'port') and cb['cores'] >= 1 and cb['value'] > 0
+    if name.startswith('r02'):           # round 2: the "betas L2 vs CPU" half of the metric
+        par = r['parity']
+        assert par['n_images'] == r['config']['global_batch']
+        assert par['betas_l2'] < par['tolerance'] and par['vertices_maxabs'] < par['tolerance']
+        assert r['cpu_baseline']['single_thread']['cores'] == 1
+
+
+def test_committed_measurement_line_has_the_contract_fields():
+    """BASELINE configs[3] (bench.py --workload measurements)."""
+    with open(osp.join(ROOT, 'profiles', 'r02g_bench_measurements_1000.json')) as f:
+        r = json.loads(f.read().strip().splitlines()[-1])
+    assert r['unit'] == 'meshes/sec' and r['config']['meshes_per_gpu'] == 1000
+    rf = r['roofline']
+    assert rf['bound'] == 'hbm' and rf['unit'] == 'GB/s' and rf['peak'] == 8000.0
+    assert abs(rf['achieved'] - rf['bytes_per_launch_group'] / rf['ms_per_launch_group'] / 1e6) < 1e-6 * rf['achieved']
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9 and rf['frac'] > 0.25
+    assert r['cpu_baseline']['kind'] == 'port' and max(r['parity']['maxabs'].values()) < 1e-4
