@@ -336,11 +336,11 @@ int conv2d_wino(ConvK k, int tm, hipStream_t s) {
   k.wgt2_bytes = (unsigned)wb;
   const int nn = k.Cout % 48 == 0 ? 3 : 4;            // 48- or 64-channel N tiles
   k.nbx = k.Cout / (16 * nn);
-  // measured on MI355X at B = 64 (profiles/conv_bench_r02b_winograd_tm1_tm2.txt): two tile groups
-  // win once the K loop is long enough to amortise the larger prologue (Cin >= 96: 192 -> 192
-  // @14x14 67 -> 57 us, 256 -> 48 @56x56 292 -> 272 us) and the grid still has >= 1.5 workgroups
-  // per CU; 48 -> 48 @56x56 (3 chunks) and 384 -> 384 @7x7 (256 workgroups) are faster with one
-  if (tm == 0) tm = (k.Cin >= 96 && (long)((k.wino_tiles + 31) / 32) * k.nbx >= 384) ? 2 : 1;
+  // measured on MI355X at B = 64 (profiles/conv_bench_r02k_winograd_tm1_tm2.txt): two tile groups
+  // (every B fragment used twice) win once the K loop is deep (192 -> 192 @14x14: 65 -> 57 us) and
+  // the grid still has >= 1.5 workgroups per CU; 48 -> 48 / 96 -> 96 (3 / 6 chunks: 64 vs 67, 59 vs
+  // 61 us) and 384 -> 384 @7x7 (256 workgroups with two groups: 64 vs 73 us) are faster with one
+  if (tm == 0) tm = (k.Cin >= 192 && (long)((k.wino_tiles + 31) / 32) * k.nbx >= 384) ? 2 : 1;
   if (nn == 4) tm = 1;                                 // 64 accumulator + 64 B-fragment registers
   k.nby = (k.wino_tiles + 16 * tm - 1) / (16 * tm);
   // transformed filters larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
