@@ -107,7 +107,6 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
     for (int k = 0; k < 4; ++k) xok[s][k] = (unsigned)(x0 + k) < (unsigned)W;
   }
   const int pix_stride = p.in_ld * 4;
-  const float so = r == 3 ? -1.f : 1.f, sp = (r == 1 || r == 3) ? 1.f : -1.f;
   const int fsw = (tile_s ^ (tile_s >> 1)) & 3;
   const int st_off = tile_s * 64 + (((c4 ^ fsw ^ r) & 3) << 4) + 4 * r * PSTR;   // + j * PSTR
 
@@ -119,10 +118,13 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
   const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void *>(p.res ? p.res : p.in), 0, 0x7ffffffe, 0x00020000);
   const bool has_res = p.res != nullptr;
-  // epilogue item of this thread for tile group mt: (tile tl, channels col .. col + 3)
-  const int c4o = t % N4, tl = t / N4;
-  const int col = n_blk + c4o * 4;
-  auto item = [&](int mt, bool (&ok)[4], int (&pixi)[4]) {
+  // epilogue item of this thread for tile group mt: (tile tl, channels col .. col + 3); tl / col
+  // are recomputed where needed instead of being kept live across the K loop (the 16-tile
+  // kernel sits exactly at its 168-register budget: three spilled registers cost 9.6 MB of
+  // scratch traffic per launch)
+  auto item = [&](int mt, bool (&ok)[4], int (&pixi)[4], int &col) {
+    const int c4o = t % N4, tl = t / N4;
+    col = n_blk + c4o * 4;
     const int tile = m_blk + 16 * mt + tl;
     const bool active = t < 16 * N4 && tile < T && col < p.Cout;
     const int tt_ = active ? tile : 0;
@@ -150,8 +152,8 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
 #pragma unroll
       for (int s = 0; s < TM; ++s) {
         bool ok[4];
-        int pixi[4];
-        item(s, ok, pixi);
+        int pixi[4], col;
+        item(s, ok, pixi, col);
         int off[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {       // plain selects: no divergent branch around a load
@@ -165,6 +167,9 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
     }
   };
   auto lstore = [&](int buf) {
+    // signs of B^T for this thread's patch row (recomputed: two registers less across the K loop)
+    const int rr = threadIdx.x & 3;
+    const float so = rr == 3 ? -1.f : 1.f, sp = (rr & 1) ? 1.f : -1.f;
 #pragma unroll
     for (int s = 0; s < TM; ++s) {
       f32x4 d[4], tr[4];
@@ -252,8 +257,9 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt) {
     bool okk[4];
-    int pixi[4];
-    item(mt, okk, pixi);
+    int pixi[4], col;
+    item(mt, okk, pixi, col);
+    const int c4o = t % N4, tl = t / N4;
     const bool active = okk[0];              // pixel (0,0) of a live tile is always inside
     bool ok[2][2];
     long pix[2][2];

@@ -487,7 +487,8 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
   }
   M2_STAMP(12);
   // ---- perimeter: the edges of both chains, one edge per lane and round ----
-  float perim = 0.f;
+  // (summed in float64: the result does not depend on how the edges fall onto the lanes)
+  double perim_d = 0.0;
   const int ml = len[0], mu = len[1];
   const int ne = (ml > 0 ? ml - 1 : 0) + (mu > 0 ? mu - 1 : 0);
   for (int e0 = 0; e0 < ne; e0 += 64) {
@@ -501,8 +502,12 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
       const float dx = px[c] - px[a], dy = py[c] - py[a], dz = pz[c] - pz[a];
       elen = sqrtf(dx * dx + dy * dy + dz * dz);
     }
-    perim += wave_reduce_sum(elen);
+    double v = (double)elen;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    perim_d += v;
   }
+  const float perim = (float)perim_d;
   M2_STAMP(13);
   if (lane == 0) {
     out[b * 5 + 2 + pl] = perim;
