@@ -112,7 +112,13 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
   const int esz = dtype == SHAPY_DTYPE_BF16 ? 2 : 4;
   const float *wf32 = reinterpret_cast<const float *>(weights);   // biases + stem weights
   Lanes *L = nullptr;
+  // The side streams and their fork / join events are one set per device, shared by every
+  // caller: the whole issue of a forward (and a graph capture of it) holds this lock, so two host
+  // threads or two caller streams cannot interleave their fork / join records on them.
+  static std::mutex run_mu;
+  std::unique_lock<std::mutex> run_lock(run_mu, std::defer_lock);
   if (multi_stream) {
+    run_lock.lock();
     int rc = get_lanes(&L);
     if (rc) return rc;
   }
@@ -169,7 +175,10 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
       d.reserved0 = 0;
       d.wgt_wino = (dtype == SHAPY_DTYPE_F32 && o.wino_off >= 0) ? wf32 + o.wino_off : nullptr;
       int rc = conv2d(d, s);
-      if (rc) return rc;
+      if (rc) {
+        if (multi_stream) join_all();        // leave no forked lane unjoined behind an error
+        return rc;
+      }
     } else if (o.type == SHAPY_OP_STEM) {
       if (o.Cin != 3 || o.Cout != 64 || o.ksize != 3 || o.stride != 2) return SHAPY_EINVAL;
       const long npix = (long)B * o.Ho * o.Wo;

@@ -160,8 +160,7 @@ def _pack(items):
         for (o, s, _) in live:
             if off + size <= o:
                 break
-            off = max(off, o + s)
-        off = (off + 7) // 8 * 8
+            off = max(off, (o + s + 7) // 8 * 8)      # aligned BEFORE the next gap test
         obj.off = off
         live.append((off, size, end))
         total = max(total, off + size)
@@ -695,6 +694,11 @@ class HighResolutionNet(VersionedWeights, nn.Module):
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f'expected [B,3,H,W], got {tuple(x.shape)}')
+        if self.training:
+            # BatchNorm is folded from the running statistics: this engine only implements the
+            # inference semantics (the reference would use batch statistics in train mode)
+            raise RuntimeError('HighResolutionNet runs in eval mode only on the HIP path: call '
+                               '.eval() (BatchNorm is folded from its running statistics)')
         _lib.require_cuda(x, 'images')
         lib = _lib.load()
         B, _, H, W = x.shape

@@ -184,6 +184,9 @@ class IterativeRegression(VersionedWeights, nn.Module):
         """-> (parameters: list of [B,P] per stage, deltas: [stage-0 delta])
         (networks.py:536-592)."""
         _lib.require_cuda(features, 'features')
+        if self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in self.module.modules()):
+            raise RuntimeError('IterativeRegression runs in eval mode only on the HIP path: the '
+                               'collapsed affine map has no dropout (call .eval())')
         lib = _lib.load()
         B, F = features.shape
         if F % 4:
