@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64) void smplx_pose_kernel(PoseK k) {
   __shared__ float R[64 * 9];
   __shared__ float Jl[64 * 3];
   __shared__ float G[64 * 12];
+  __shared__ int Par[64];
   const int b = blockIdx.x, j = threadIdx.x;
   if (j < k.J) {
     float r[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
@@ -169,14 +170,26 @@ __global__ __launch_bounds__(64) void smplx_pose_kernel(PoseK k) {
     }
   }
   for (int i = k.P + j; i < k.Ppad; i += 64) k.pf[(long)b * k.Ppad + i] = 0.f;
+  // parents and tree depth of every joint in LDS: the chain below used to read k.parents[i] from
+  // global memory inside a serial 54-step loop on lane 0 (a dependent ~0.5 us load per joint)
+  Par[j] = j < k.J ? k.parents[j] : -1;
   __syncthreads();
+  int depth = 0;
+  if (j < k.J)
+    for (int a = j; a > 0 && depth < 64; a = Par[a]) ++depth;
+  // batch_rigid_transform (lbs.py:242-295): G_i = G_parent * [R_i | J_i - J_parent], one tree
+  // level per step, the joints of a level in parallel (same per-joint arithmetic as the serial
+  // walk: every G_i is one 3x4 product of its parent's G and its own local transform)
   if (j == 0) {
-    // batch_rigid_transform (lbs.py:242-295): G_i = G_parent * [R_i | J_i - J_parent]
 #pragma unroll
     for (int i = 0; i < 9; ++i) G[(i / 3) * 4 + (i % 3)] = R[i];
     G[3] = Jl[0]; G[7] = Jl[1]; G[11] = Jl[2];
-    for (int i = 1; i < k.J; ++i) {
-      const int pa = k.parents[i];
+  }
+  __syncthreads();
+  for (int d = 1; d < 64; ++d) {
+    if (__ballot(depth >= d) == 0ull) break;
+    if (depth == d) {
+      const int i = j, pa = Par[i];
       const float *Gp = G + pa * 12;
       const float *Ri = R + i * 9;
       const float rel[3] = {Jl[i * 3] - Jl[pa * 3], Jl[i * 3 + 1] - Jl[pa * 3 + 1],
@@ -192,6 +205,9 @@ __global__ __launch_bounds__(64) void smplx_pose_kernel(PoseK k) {
                         Gp[r * 4 + 3];
       }
     }
+    __syncthreads();
+  }
+  if (j == 0) {
     // dynamic-landmark LUT row (lbs.py:28-41): rel = R[c0] (R[c1] (... I)), applied in order
     if (k.dyn_row) {
       float rel[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, tmp[9];

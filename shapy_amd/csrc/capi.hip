@@ -64,8 +64,8 @@ extern "C" int shapy_hrnet_graph_create(const ShapyOp *ops, int n_ops, const voi
     g = new HrnetGraph();
     rc = (int)hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
   }
-  if (graph) hipGraphDestroy(graph);
-  hipStreamDestroy(cs);
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipStreamDestroy(cs);
   if (rc != 0) {
     delete g;
     return rc;
@@ -83,7 +83,7 @@ extern "C" int shapy_hrnet_graph_launch(void *graph, void *stream) {
 extern "C" int shapy_hrnet_graph_destroy(void *graph) {
   if (!graph) return SHAPY_OK;
   HrnetGraph *g = static_cast<HrnetGraph *>(graph);
-  if (g->exec) hipGraphExecDestroy(g->exec);
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
   delete g;
   return SHAPY_OK;
 }

@@ -137,6 +137,9 @@ WINO_CASES = [
     (2, 12, 12, 64, 64, True, True),       # 64-channel N tiles (layer1's 64 -> 64)
     (1, 7, 7, 512, 512, False, True),      # the head's 512 -> 512
     (2, 9, 9, 32, 128, True, False),
+    (1, 6, 6, 48, 48, False, False),       # all-K staging (Cin = 48), no residual, partial workgroup
+    (2, 10, 10, 48, 96, True, True),       # all-K staging, 2 N blocks
+    (1, 5, 7, 64, 128, False, True),       # all-K staging of the 64-wide variant (Cin = 64)
 ]
 
 

@@ -67,7 +67,7 @@ def main():
         wu = None
         for tile in args.tiles.split(','):
             d = _lib.ShapyConv()
-            if tile in ('wino', 'wino1', 'wino2'):     # Winograd F(2x2,3x3) where it applies
+            if tile in ('wino', 'wino1', 'wino2', 'winochunk'):     # Winograd F(2x2,3x3) where it applies
                 from shapy_amd.utils import winograd
                 if args.dtype != 'f32' or not winograd.eligible(ks, st, pad, Cin, Cout, ups):
                     continue
@@ -81,7 +81,7 @@ def main():
             d.Ho, d.Wo, d.Cout = Ho, Wo, Cout
             d.ksize, d.stride, d.pad = ks, st, pad
             d.out_ld = Cout; d.out_coff = 0; d.res_ld = Cout if has_res else 0; d.res_coff = 0
-            d.relu = int(relu); d.ups = ups; d.tile = {'wino': 0, 'wino1': 0x4000, 'wino2': 0x8000}[tile] if tile.startswith('wino') else _lib.TILES[tile]
+            d.relu = int(relu); d.ups = ups; d.tile = {'wino': 0, 'wino1': 0x4000, 'wino2': 0x8000, 'winochunk': 0x20000}[tile] if tile.startswith('wino') else _lib.TILES[tile]
             d.dtype = {'f32': _lib.DTYPE_F32, 'bf16': _lib.DTYPE_BF16, 'f32x6': _lib.DTYPE_F32X6}[args.dtype]
             rc = 0
             for _ in range(2):
