@@ -288,6 +288,7 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   k.swz = (d.tile & 0x400) ? 0 : 1;
   k.no_nslab = (d.tile & 0x10000) ? 1 : 0;
   k.no_allk = (d.tile & 0x20000) ? 1 : 0;
+  k.dbg = 0;
   k.stagger_us = 0; k.stagger_slots = 0;
   if (d.dtype == SHAPY_DTYPE_F32 && !(d.tile & 0x2000) && conv_wino_eligible(k))
     return conv2d_wino(k, (d.tile & 0x4000) ? 1 : (d.tile & 0x8000) ? 2 : 0, s);

@@ -49,9 +49,13 @@ __device__ unsigned long long g_wino_times[16];
   do {                                                                              \
     if (blockIdx.x == gridDim.x / 2 + 1 && threadIdx.x == 0) g_wino_times[slot] = wall_clock64(); \
   } while (0)
+#define WINO_DBG(bit) (p.dbg & (bit))
 #else
 #define WINO_STAMP(slot) do {} while (0)
+#define WINO_DBG(bit) false
 #endif
+
+__device__ __forceinline__ bool v_dbg_skip(const f32x4 &v) { return v[0] != 12345.678f; }
 
 // KC > 0: the layer has exactly KC K chunks (Cin = 16 KC) and ALL of them are staged in the
 // prologue (KC V buffers, which fit into the memory the accumulator exchange needs anyway): the K
@@ -85,6 +89,7 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
   WINO_STAMP(0);
   const int wg = conv_tile_index(p);
   const int m_blk = (wg / p.nbx) * MT, n_blk = (wg % p.nbx) * N;
+  const int m_ld = WINO_DBG(2) ? 0 : m_blk;           // ablation: every workgroup loads tile group 0
   const int H = p.Hi, W = p.Wi;
   const int TW = (W + 1) >> 1, TH = (H + 1) >> 1;
   const int T = p.wino_tiles;
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
   bool xok[TM][4], rowok[TM];
 #pragma unroll
   for (int s = 0; s < TM; ++s) {
-    const int tile = m_blk + 16 * s + tile_s;
+    const int tile = m_ld + 16 * s + tile_s;
     const int tt = tile < T ? tile : 0;
     const int tx = tt % TW;
     const int tq = tt / TW;
@@ -205,8 +210,9 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
 
   u32x4 bfr[4][NN];
   auto bload = [&](int pp, int cc, bool live) {
-    const int base = live ? u_lane + (4 * wave + pp) * u_pos_stride + cc * u_chunk_stride
-                          : OOB - 4096;
+    int base = live ? u_lane + (4 * wave + pp) * u_pos_stride + cc * u_chunk_stride : OOB - 4096;
+    if (WINO_DBG(1)) base = live ? u_lane : OOB - 4096;           // ablation: one hot 3 KB of filters
+    if (WINO_DBG(16) && cc > 0) return;                           // ablation: no filter refills at all
 #pragma unroll
     for (int n = 0; n < NN; ++n)
       bfr[pp][n] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, base + n * 1024, 0, 0);
@@ -240,9 +246,10 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
         for (int m = 0; m < TM; ++m)
 #pragma unroll
           for (int n = 0; n < NN; ++n)
-            acc[pp][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                __uint_as_float(af[pp & 1][m][kk]), __uint_as_float(bfr[pp][n][kk]), acc[pp][m][n],
-                0, 0, 0);
+            if (!WINO_DBG(8) || kk == 0)
+              acc[pp][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                  __uint_as_float(af[pp & 1][m][kk]), __uint_as_float(bfr[pp][n][kk]),
+                  acc[pp][m][n], 0, 0, 0);
       // keep the refill of this position's B fragments HERE (hipcc otherwise sinks all 12 loads
       // to the end of the iteration, one LDS store + barrier before their first use)
       __builtin_amdgcn_sched_barrier(0);
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-          if (!ok[a][bb]) continue;
+          if (!ok[a][bb] || (WINO_DBG(4) && v_dbg_skip(y[a][bb]))) continue;
           f32x4 v = y[a][bb] + rv[a][bb];
           if (p.relu) {
 #pragma unroll
@@ -392,6 +399,9 @@ int conv2d_wino(ConvK k, int tm, hipStream_t s) {
   if (tm == 0) tm = (k.Cin >= 192 && (long)((k.wino_tiles + 31) / 32) * k.nbx >= 384) ? 2 : 1;
   if (nn == 4) tm = 1;                                 // 64 accumulator + 64 B-fragment registers
   k.nby = (k.wino_tiles + 16 * tm - 1) / (16 * tm);
+#ifdef SHAPY_WINO_TIMING
+  k.dbg = getenv("SHAPY_WINO_DBG") ? atoi(getenv("SHAPY_WINO_DBG")) : 0;
+#endif
   // transformed filters larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
   if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt2_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
   {
