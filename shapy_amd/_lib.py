@@ -66,6 +66,8 @@ for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: con
     TILES[_k + '+wtm1'] = _v | 0x4000         # Winograd: 16 tiles per workgroup
     TILES[_k + '+wtm2'] = _v | 0x8000         # Winograd: 32 tiles per workgroup
     TILES[_k + '+nonslab'] = _v | 0x10000     # keep the m-major XCD order for large weights
+    TILES[_k + '+pd3'] = _v | 0x40000         # implicit GEMM: 3 chunks of loads in flight (bf16 default)
+    TILES[_k + '+pd1'] = _v | 0x80000         # ... 1 chunk (float32 default)
     TILES[_k + '+noallk'] = _v | 0x20000      # Winograd: K loop chunk by chunk even for Cin = 48 / 64
 
 #: every symbol include/shapy_hip.h declares: (restype, argtypes)

@@ -22,7 +22,11 @@
 
 namespace shapy {
 
-template <typename T, int BM, int BN, int WM, int WN, int UPS, int KQ>
+// PD = chunks of global loads in flight per thread (register sets).  PD = 1: the next chunk is
+// requested before the MFMAs of the current one, i.e. a chunk may take no less than a load latency
+// (~1 us); with bf16 operands a chunk is 3-6 MFMAs per wave (50-100 ns), so the K loop of the
+// small-grid layers is one serial chain of load latencies.  PD = 3 keeps three chunks in flight.
+template <typename T, int BM, int BN, int WM, int WN, int UPS, int KQ, int PD = 1>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(KQ == 4 || KQ == 8, "16-byte slots per staged row");
@@ -76,25 +80,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     b_off[i] = ((r < BN) && (n < p.Cout)) ? n * Kw * ESZ + kq * 16 : OOB;
   }
 
-  u32x4 a_reg[AR], b_reg[BR];
+  u32x4 a_reg[PD][AR], b_reg[PD][BR];
 
   // chunk iterator state for the NEXT chunk to be fetched
   int kh = 0, kw = 0, c0 = 0;
   const int n_chunks = p.ks * p.ks * (p.Cin / BK);
 
-  auto gload = [&]() {
+  auto gload = [&](int set) {
     const int tap_in = ((kh * p.Wi + kw) * p.in_ld + c0) * ESZ;
     const int tap_w = ((kh * p.ks + kw) * p.Cin + c0) * ESZ;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const bool ok = (unsigned)(a_h[i] + kh) < (unsigned)p.Hi &&
                       (unsigned)(a_w[i] + kw) < (unsigned)p.Wi;
-      a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + tap_in : OOB, 0, 0);
+      a_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(
+          rs_in, (ok && kh < p.ks) ? a_off[i] + tap_in : OOB, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i)
-      b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(
-          rs_w, b_off[i] == OOB ? OOB : b_off[i] + tap_w, 0, 0);
+      b_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(
+          rs_w, (b_off[i] == OOB || kh >= p.ks) ? OOB : b_off[i] + tap_w, 0, 0);
     c0 += BK;
     if (c0 == p.Cin) {
       c0 = 0;
@@ -108,14 +113,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     const int r = lrow + RPP * i;
     st_off[i] = r * ROWB + ((kq ^ ((r ^ (r >> 1)) & (KQ - 1))) << 4);
   }
-  auto lstore = [&]() {
+  auto lstore = [&](int set) {
     char *A = lds;
     char *Bt = lds + BM * ROWB;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<u32x4 *>(A + st_off[i]) = a_reg[i];
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<u32x4 *>(A + st_off[i]) = a_reg[set][i];
 #pragma unroll
     for (int i = 0; i < BR; ++i)
-      if (lrow + RPP * i < BN) *reinterpret_cast<u32x4 *>(Bt + st_off[i]) = b_reg[i];
+      if (lrow + RPP * i < BN) *reinterpret_cast<u32x4 *>(Bt + st_off[i]) = b_reg[set][i];
   };
 
   f32x4 acc[TM][TN];
@@ -133,13 +138,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   const int a_base = wm * (BM / WM) * ROWB;
   const int b_base = BM * ROWB + wn * (BN / WN) * ROWB;
 
-  gload();
-  lstore();
-  __syncthreads();
-
-  for (int kc = 0; kc < n_chunks; ++kc) {
-    const bool more = kc + 1 < n_chunks;
-    if (more) gload();
+  auto compute = [&]() {
     const char *L = lds;
 #pragma unroll
     for (int sub = 0; sub < KQ / 4; ++sub) {
@@ -171,9 +170,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
                 0, 0);
       }
     }
-    __syncthreads();                         // everybody is done reading the buffer
-    if (more) lstore();
+  };
+
+  if constexpr (PD == 1) {
+    gload(0);
+    lstore(0);
     __syncthreads();
+    for (int kc = 0; kc < n_chunks; ++kc) {
+      const bool more = kc + 1 < n_chunks;
+      if (more) gload(0);
+      compute();
+      __syncthreads();                         // everybody is done reading the buffer
+      if (more) lstore(0);
+      __syncthreads();
+    }
+  } else {
+    // PD register sets in flight; set (kc % PD) holds chunk kc.  Loads past the last chunk are
+    // issued with out-of-range offsets (they return zeros and are never staged), so that there is
+    // no branch around a load and the compiler's vmcnt bookkeeping stays exact.
+#pragma unroll
+    for (int d = 0; d < PD; ++d) gload(d);
+    lstore(0);
+    gload(0);                                  // chunk PD
+    __syncthreads();
+    // (the trip count is rounded up to a multiple of PD: the extra chunks are zeros)
+    for (int kc = 0; kc < n_chunks; kc += PD) {
+#pragma unroll
+      for (int d = 0; d < PD; ++d) {
+        compute();
+        __syncthreads();                       // everybody is done reading the buffer
+        lstore((d + 1) % PD);
+        __builtin_amdgcn_sched_barrier(0);
+        gload((d + 1) % PD);                   // chunk kc + d + 1 + PD
+        __syncthreads();
+      }
+    }
   }
 
   if constexpr (VEC) {
@@ -194,8 +225,12 @@ static int launch(ConvK k, hipStream_t s) {
   k.nby = (k.M + BM - 1) / BM;
   // weights larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
   if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, UPS, KQ>), dim3(k.nbx * k.nby), dim3(256),
-                     0, s, k);
+  if (UPS == 1 && k.pd3)
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, 1, KQ, 3>), dim3(k.nbx * k.nby),
+                       dim3(256), 0, s, k);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, UPS, KQ>), dim3(k.nbx * k.nby),
+                       dim3(256), 0, s, k);
   return (int)hipGetLastError();
 }
 
@@ -289,6 +324,9 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   k.no_nslab = (d.tile & 0x10000) ? 1 : 0;
   k.no_allk = (d.tile & 0x20000) ? 1 : 0;
   k.dbg = 0;
+  // three chunks of global loads in flight: bf16 always (its chunks are 50-100 ns of MFMAs);
+  // float32 on request (tile flag 0x40000, A/B benches)
+  k.pd3 = (bf16 || (d.tile & 0x40000)) && !(d.tile & 0x80000) ? 1 : 0;
   k.stagger_us = 0; k.stagger_slots = 0;
   if (d.dtype == SHAPY_DTYPE_F32 && !(d.tile & 0x2000) && conv_wino_eligible(k))
     return conv2d_wino(k, (d.tile & 0x4000) ? 1 : (d.tile & 0x8000) ? 2 : 0, s);
