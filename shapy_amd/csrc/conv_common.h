@@ -170,15 +170,60 @@ __device__ __forceinline__ void conv_epilogue(const ConvK &p, f32x4 (&acc)[TM][T
 // LDS bytes a workgroup needs for conv_epilogue_vec (4 waves, wave tile 16 TM x 16 TN)
 constexpr int conv_epilogue_vec_bytes(int TM, int TN) { return 4 * (16 * TM) * (16 * TN + 4) * 4; }
 
-// float32 epilogue with full-line stores.  The MFMA C layout gives a lane one column and four
-// rows, i.e. a wave store instruction writes 64-byte row segments; here every wave first parks
-// its (bias-added) tile in a private LDS region and reads it back row-major, so that residual
-// loads and stores are 16 bytes per lane over whole 128..256-byte row segments.  No workgroup
-// barrier: a wave only reads what it wrote itself (the staging buffer is free after the K loop).
-template <int TM, int TN>
+// Epilogue with full-line stores.  The MFMA C layout gives a lane one column and four rows, i.e.
+// a wave store instruction writes 64-byte (f32) / 32-byte (bf16) row segments; here every wave
+// first parks its (bias-added) tile in a private LDS region and reads it back row-major, so that
+// residual loads and stores are 16 bytes per lane (4 f32 / 8 bf16 channels) over whole
+// 128..256-byte row segments.  No workgroup barrier: a wave only reads what it wrote itself (the
+// staging buffer is free after the K loop).  UPS > 1: conv1x1 + BN + nearest Upsample(UPS) + add
+// (+ ReLU) -- the 16-byte channel group goes to a UPS x UPS block of output pixels (the scalar
+// scatter wrote 2-byte pieces of 32-byte segments in bf16: 193 us for the 384 -> 64 x8 layer at
+// B = 32, profiles/conv_bench_r02q_bf16_b32_pd3_vs_pd1.txt).  `res` may alias `out` (in-place
+// accumulation of the fuse layers): every 16-byte group is read and written by the same lane.
+template <typename T>
+struct VecIO;
+template <>
+struct VecIO<F32> {
+  static constexpr int CG = 4;
+  static __device__ __forceinline__ void load(const void *p, long i, float (&v)[4]) {
+    const f32x4 x = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p) + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = x[e];
+  }
+  static __device__ __forceinline__ void store(void *p, long i, const float (&v)[4]) {
+    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p) + i) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+};
+template <>
+struct VecIO<BF16> {
+  static constexpr int CG = 8;
+  static __device__ __forceinline__ void load(const void *p, long i, float (&v)[8]) {
+    const u32x4 x = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned short *>(p) + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = __uint_as_float(x[e] << 16);
+      v[2 * e + 1] = __uint_as_float(x[e] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store(void *p, long i, const float (&v)[8]) {
+    u32x4 x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned lo = __float_as_uint(v[2 * e]), hi = __float_as_uint(v[2 * e + 1]);
+      lo += 0x7fffu + ((lo >> 16) & 1u);                // round to nearest even (as BF16::store)
+      hi += 0x7fffu + ((hi >> 16) & 1u);
+      x[e] = (lo >> 16) | (hi & 0xffff0000u);
+    }
+    *reinterpret_cast<u32x4 *>(reinterpret_cast<unsigned short *>(p) + i) = x;
+  }
+};
+
+template <typename T, int TM, int TN, int UPS>
 __device__ __forceinline__ void conv_epilogue_vec(const ConvK &p, f32x4 (&acc)[TM][TN],
                                                   char *lds_wave, int row0, int col0, int lane) {
-  constexpr int R = 16 * TM, C = 16 * TN, LDC = C + 4, C4 = C / 4;
+  constexpr int CG = VecIO<T>::CG;
+  constexpr int R = 16 * TM, C = 16 * TN, LDC = C + 4, NG = C / CG;
+  static_assert(C % CG == 0, "wave tile width is a multiple of the channel group");
   float *s = reinterpret_cast<float *>(lds_wave);
   const int cl = lane & 15, rl = (lane >> 4) * 4;
 #pragma unroll
@@ -193,30 +238,61 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvK &p, f32x4 (&acc)[T
   // the tile is read back by other lanes of the same wave: LDS executes a wave's instructions
   // in order; the asm keeps the compiler from moving the reads above the writes
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const float *res = reinterpret_cast<const float *>(p.res);
-  float *out = reinterpret_cast<float *>(p.out);
+  const int WoU = p.Wo * UPS;
 #pragma unroll
-  for (int q0 = 0; q0 < R * C4; q0 += 64) {
+  for (int q0 = 0; q0 < R * NG; q0 += 64) {
     const int q = q0 + lane;
-    if ((R * C4) % 64 != 0 && q >= R * C4) break;
-    const int rr = q / C4, c4 = q % C4;
-    const int row = row0 + rr, col = col0 + c4 * 4;
+    if ((R * NG) % 64 != 0 && q >= R * NG) break;
+    const int rr = q / NG, cg = q % NG;
+    const int row = row0 + rr, col = col0 + cg * CG;
     if (row >= p.M || col >= p.Cout) continue;
-    f32x4 v = *reinterpret_cast<const f32x4 *>(s + rr * LDC + c4 * 4);
-    float *o = out + (long)row * p.out_ld + p.out_coff + col;
-    const float *rp = res ? res + (long)row * p.res_ld + p.res_coff + col : nullptr;
-    if (col + 3 < p.Cout) {
-      if (rp) v += *reinterpret_cast<const f32x4 *>(rp);
-      if (p.relu) {
+    float v[CG];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    for (int e = 0; e < CG; e += 4) {
+      const f32x4 x = *reinterpret_cast<const f32x4 *>(s + rr * LDC + cg * CG + e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[e + k] = x[k];
+    }
+    long pix0 = row;
+    if constexpr (UPS > 1) {
+      const int wo = row % p.Wo;
+      const int tq = row / p.Wo;
+      const int ho = tq % p.Ho;
+      const int b = tq / p.Ho;
+      pix0 = ((long)(b * p.Ho + ho) * UPS) * WoU + (long)wo * UPS;
+    }
+    if (col + CG - 1 < p.Cout) {
+#pragma unroll
+      for (int dy = 0; dy < UPS; ++dy) {
+        float rv[UPS][CG];
+#pragma unroll
+        for (int dx = 0; dx < UPS; ++dx) {
+          if (p.res) {
+            VecIO<T>::load(p.res, (pix0 + (long)dy * WoU + dx) * p.res_ld + p.res_coff + col, rv[dx]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < CG; ++e) rv[dx][e] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int dx = 0; dx < UPS; ++dx) {
+          float o[CG];
+#pragma unroll
+          for (int e = 0; e < CG; ++e) {
+            o[e] = v[e] + rv[dx][e];
+            if (p.relu) o[e] = fmaxf(o[e], 0.f);
+          }
+          VecIO<T>::store(p.out, (pix0 + (long)dy * WoU + dx) * p.out_ld + p.out_coff + col, o);
+        }
       }
-      *reinterpret_cast<f32x4 *>(o) = v;
     } else {
-      for (int e = 0; e < 4 && col + e < p.Cout; ++e) {
-        const float x = v[e] + (rp ? rp[e] : 0.f);
-        o[e] = p.relu ? fmaxf(x, 0.f) : x;
-      }
+      for (int dy = 0; dy < UPS; ++dy)
+        for (int dx = 0; dx < UPS; ++dx)
+          for (int e = 0; e < CG && col + e < p.Cout; ++e) {
+            const long pi = pix0 + (long)dy * WoU + dx;
+            const float x = v[e] + (p.res ? T::load(p.res, pi * p.res_ld + p.res_coff + col + e) : 0.f);
+            T::store(p.out, pi * p.out_ld + p.out_coff + col + e, p.relu ? fmaxf(x, 0.f) : x);
+          }
     }
   }
 }

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   constexpr int BR = (BN + RPP - 1) / RPP;   // B rows staged per thread (guarded)
   // ONE staging buffer, two barriers per chunk: the barriers cost nothing measurable, the
   // LDS footprint does (8 workgroups per CU instead of 5 with 32-float chunks: +4.9 % end to end)
-  constexpr bool VEC = UPS == 1 && sizeof(typename T::elem) == 4;   // vector epilogue available
+  constexpr bool VEC = true;                   // vector epilogue (16-byte rows) available
   constexpr int LDS_STAGE = (BM + BN) * ROWB, LDS_EPI = VEC ? conv_epilogue_vec_bytes(TM, TN) : 0;
   __shared__ __attribute__((aligned(16))) char lds[LDS_STAGE > LDS_EPI ? LDS_STAGE : LDS_EPI];
 
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 
   if constexpr (VEC) {
     if (p.vec4) {
-      conv_epilogue_vec<TM, TN>(p, acc, lds + wave * (LDS_EPI / 4), m_blk + wm * (BM / WM),
+      conv_epilogue_vec<T, TM, TN, UPS>(p, acc, lds + wave * (LDS_EPI / 4), m_blk + wm * (BM / WM),
                                 n_blk + wn * (BN / WN), lane);
       return;
     }
@@ -305,10 +305,11 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   k.Cout = d.Cout; k.ks = d.ksize; k.stride = d.stride; k.pad = d.pad;
   k.out_ld = d.out_ld; k.out_coff = d.out_coff; k.res_ld = d.res_ld; k.res_coff = d.res_coff;
   k.relu = d.relu; k.ups = d.ups;
-  // float32 rows of out / res start on 16-byte boundaries: the epilogue may use 16-byte accesses
-  k.vec4 = d.dtype != SHAPY_DTYPE_BF16 && ((d.out_ld | d.out_coff) & 3) == 0 &&
-           ((uintptr_t)d.out & 15) == 0 &&
-           (!d.res || (((d.res_ld | d.res_coff) & 3) == 0 && ((uintptr_t)d.res & 15) == 0));
+  // rows of out / res start on 16-byte boundaries (4 f32 / 8 bf16 channels): the epilogue may use
+  // 16-byte accesses
+  const int cgm = eps - 1;
+  k.vec4 = ((d.out_ld | d.out_coff) & cgm) == 0 && ((uintptr_t)d.out & 15) == 0 &&
+           (!d.res || (((d.res_ld | d.res_coff) & cgm) == 0 && ((uintptr_t)d.res & 15) == 0));
   const unsigned long long in_bytes = (unsigned long long)esz * d.B * d.Hi * d.Wi * d.in_ld;
   k.Kp = (d.ksize * d.ksize * d.Cin + 31) / 32 * 32;
   const unsigned long long wgt_bytes =

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(ConvK p) {
 
   if constexpr (UPS == 1) {
     if (p.vec4) {
-      conv_epilogue_vec<TM, TN>(p, acc, lds + wave * (LDS_EPI / 4), m_blk + wm * (BM / WM),
+      conv_epilogue_vec<F32, TM, TN, 1>(p, acc, lds + wave * (LDS_EPI / 4), m_blk + wm * (BM / WM),
                                 n_blk + wn * (BN / WN), lane);
       return;
     }
