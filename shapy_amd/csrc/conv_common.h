@@ -44,6 +44,7 @@ struct ConvK {
   int wino_tiles;               // B * ceil(H/2) * ceil(W/2)
   int no_nslab;                 // tuning: keep the m-major XCD order for large weights
   int no_allk;                  // tuning: Winograd K loop always chunk by chunk
+  int flat;                     // bf16, Cin % 32 != 0: flat-K kernel
   int pd3;                      // implicit GEMM: three chunks of global loads in flight
   int dbg;                      // -DSHAPY_WINO_TIMING builds only: ablation mask (wrong results)
   int stagger_us, stagger_slots;  // Winograd: start delay per resident-workgroup slot (conv_wino.hip)

@@ -26,7 +26,10 @@ namespace shapy {
 // requested before the MFMAs of the current one, i.e. a chunk may take no less than a load latency
 // (~1 us); with bf16 operands a chunk is 3-6 MFMAs per wave (50-100 ns), so the K loop of the
 // small-grid layers is one serial chain of load latencies.  PD = 3 keeps three chunks in flight.
-template <typename T, int BM, int BN, int WM, int WN, int UPS, int KQ, int PD = 1>
+// FLAT: K = ks*ks*Cin is consumed as ONE flat index (chunks may straddle filter taps; every 16-byte
+// slot still lies inside one tap because Cin is a multiple of the slot width).  Lets bf16 run the
+// 48-channel branch without padding its tensors to 64 channels (Cin % 32 != 0).
+template <typename T, int BM, int BN, int WM, int WN, int UPS, int KQ, int PD = 1, bool FLAT = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(KQ == 4 || KQ == 8, "16-byte slots per staged row");
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     const int ho = tq % p.Ho;
     const int b = tq / p.Ho;
     const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-    a_off[i] = ((b * p.Hi + hi0) * p.Wi + wi0) * p.in_ld * ESZ + kq * 16;
+    a_off[i] = ((b * p.Hi + hi0) * p.Wi + wi0) * p.in_ld * ESZ + (FLAT ? 0 : kq * 16);
     a_h[i] = m < p.M ? hi0 : -0x40000000;
     a_w[i] = wi0;
   }
@@ -77,18 +80,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   for (int i = 0; i < BR; ++i) {
     const int r = lrow + RPP * i;
     const int n = n_blk + r;
-    b_off[i] = ((r < BN) && (n < p.Cout)) ? n * Kw * ESZ + kq * 16 : OOB;
+    b_off[i] = ((r < BN) && (n < p.Cout)) ? n * Kw * ESZ + (FLAT ? 0 : kq * 16) : OOB;
   }
 
   u32x4 a_reg[PD][AR], b_reg[PD][BR];
 
-  // chunk iterator state for the NEXT chunk to be fetched
-  int kh = 0, kw = 0, c0 = 0;
-  const int n_chunks = p.ks * p.ks * (p.Cin / BK);
+  // chunk iterator state for the NEXT chunk to be fetched (FLAT: per thread -- the slots of one
+  // chunk may belong to different taps; c0 / kflat = channel / flat k of this thread's slot)
+  int kh = 0, kw = 0, c0 = FLAT ? kq * T::EPS : 0, kflat = kq * T::EPS;
+  const int n_chunks = FLAT ? (Kw + BK - 1) / BK : p.ks * p.ks * (p.Cin / BK);
 
   auto gload = [&](int set) {
     const int tap_in = ((kh * p.Wi + kw) * p.in_ld + c0) * ESZ;
-    const int tap_w = ((kh * p.ks + kw) * p.Cin + c0) * ESZ;
+    const int tap_w = FLAT ? kflat * ESZ : ((kh * p.ks + kw) * p.Cin + c0) * ESZ;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const bool ok = (unsigned)(a_h[i] + kh) < (unsigned)p.Hi &&
@@ -101,8 +105,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
       b_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(
           rs_w, (b_off[i] == OOB || kh >= p.ks) ? OOB : b_off[i] + tap_w, 0, 0);
     c0 += BK;
-    if (c0 == p.Cin) {
-      c0 = 0;
+    kflat += BK;
+    if (FLAT ? c0 >= p.Cin : c0 == p.Cin) {          // FLAT: BK <= Cin, at most one tap per step
+      c0 -= p.Cin;
       if (++kw == p.ks) { kw = 0; ++kh; }
     }
   };
@@ -225,6 +230,14 @@ static int launch(ConvK k, hipStream_t s) {
   k.nby = (k.M + BM - 1) / BM;
   // weights larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
   if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
+  if constexpr (sizeof(typename T::elem) == 2 && BM == 64 && BN == 48 && UPS == 1 && KQ == 4) {
+    if (k.flat) {
+      hipLaunchKernelGGL((conv_igemm_kernel<T, 64, 48, WM, WN, 1, 4, 3, true>), dim3(k.nbx * k.nby),
+                         dim3(256), 0, s, k);
+      return (int)hipGetLastError();
+    }
+  }
+  if (k.flat) return SHAPY_EINVAL;
   if (UPS == 1 && k.pd3)
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, 1, KQ, 3>), dim3(k.nbx * k.nby),
                        dim3(256), 0, s, k);
@@ -257,6 +270,16 @@ int conv_tile_auto(int M, int Cout) {
   if (p48 < p64) return SHAPY_TILE_64x48;
   if (p64 < p48) return SHAPY_TILE_64x64;
   return mt * (p64 / 64) >= 512 ? SHAPY_TILE_64x64 : SHAPY_TILE_64x48;
+}
+
+int conv_tile_auto_bf16(int M, int Cout) {
+  // bf16 sweep at B = 32 / 64 (profiles/conv_bench_r02s_bf16_b*.txt): the f32 choice is the best
+  // or within 3 % everywhere except the 96-wide layers of the 28x28 branch, where one 96-wide N tile
+  // (A staged once instead of twice) wins: 64x96 from M = 25,088 (16 -> 14 us), 128x96 from
+  // M = 50,176 (26 -> 21 us)
+  if (Cout == 96 && M >= 40000) return SHAPY_TILE_128x96;
+  if (Cout == 96 && M >= 20000) return SHAPY_TILE_64x96;
+  return conv_tile_auto(M, Cout);
 }
 
 int conv_tile_auto_x6(int M, int Cout, int K) {
@@ -294,8 +317,11 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   const bool bf16 = d.dtype == SHAPY_DTYPE_BF16, x6 = d.dtype == SHAPY_DTYPE_F32X6;
   if (d.dtype != SHAPY_DTYPE_F32 && !bf16 && !x6) return SHAPY_EINVAL;
   const int esz = bf16 ? 2 : 4, eps = 16 / esz;          // element size, elements per slot
-  if (d.Cin <= 0 || d.Cin % (x6 ? 4 : 4 * eps) || d.in_ld % eps || d.ksize < 1 || d.stride < 1 ||
-      d.ups < 1)
+  // bf16: Cin % 32 != 0 (the unpadded 48-channel branch) takes the flat-K kernel: Cin % 8 == 0,
+  // Cin >= 32, no upsample epilogue, 64x48 tile
+  const bool flat = bf16 && d.Cin % 32 != 0;
+  if (d.Cin <= 0 || d.Cin % (x6 ? 4 : flat ? eps : 4 * eps) || d.in_ld % eps || d.ksize < 1 ||
+      d.stride < 1 || d.ups < 1 || (flat && (d.Cin < 32 || d.ups != 1)))
     return SHAPY_EINVAL;
   if (((uintptr_t)d.in | (uintptr_t)d.wgt) & 15) return SHAPY_EINVAL;
   ConvK k;
@@ -325,6 +351,7 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   k.no_nslab = (d.tile & 0x10000) ? 1 : 0;
   k.no_allk = (d.tile & 0x20000) ? 1 : 0;
   k.dbg = 0;
+  k.flat = flat ? 1 : 0;
   // three chunks of global loads in flight: bf16 always (its chunks are 50-100 ns of MFMAs);
   // float32 on request (tile flag 0x40000, A/B benches)
   k.pd3 = (bf16 || (d.tile & 0x40000)) && !(d.tile & 0x80000) ? 1 : 0;
@@ -341,13 +368,15 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   if ((d.tile & 0x200) && k.Cin % (8 * eps) == 0) kq = 8;
   if (d.tile & 0x800) kq = 4;
   int tile = (d.tile & 0xff) ? (d.tile & 0xff)
-                             : (x6 ? conv_tile_auto_x6(k.M, k.Cout, Kc) : conv_tile_auto(k.M, k.Cout));
+                             : (x6 ? conv_tile_auto_x6(k.M, k.Cout, Kc)
+                                   : bf16 ? conv_tile_auto_bf16(k.M, k.Cout) : conv_tile_auto(k.M, k.Cout));
   // few M tiles (14x14 / 7x7 maps at B = 64): halve BM so that every CU still holds several
   // workgroups (+4..12 %, profiles/conv_bench_r01h_32x64.txt)
   if (!(d.tile & 0xff) && !bf16 && !x6 && kq == 8 && k.ups == 1 && k.Cout % 64 == 0 && k.M <= 12544)
     tile = SHAPY_TILE_32x64;
   if (k.ups != 1 && tile != SHAPY_TILE_64x48 && tile != SHAPY_TILE_64x64)
     tile = (k.Cout % 64 == 0 && k.Cout % 48 != 0) ? SHAPY_TILE_64x64 : SHAPY_TILE_64x48;
+  if (flat) { tile = SHAPY_TILE_64x48; kq = 4; }
   if (x6) return conv2d_x6(k, tile, s);
   return bf16 ? dispatch<BF16>(k, tile, kq, s) : dispatch<F32>(k, tile, kq, s);
 }

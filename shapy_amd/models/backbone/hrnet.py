@@ -181,9 +181,10 @@ class _Plan:
         self._pending_barrier = False
 
     def padc(self, c):
-        """bf16 rows are consumed 32 channels at a time: 48-channel tensors are stored with 64
-        (zero weights / zero outputs in the pad channels)."""
-        return (c + 31) // 32 * 32 if self.bf16 else c
+        """bf16 rows are addressed in 16-byte slots of 8 channels (every HRNet width already is a
+        multiple of 8; widths that are not a multiple of 32 -- the 48-channel branch -- take the
+        flat-K kernel, csrc/conv_igemm.hip)."""
+        return (c + 7) // 8 * 8 if self.bf16 else c
 
     def buf(self, H, W, C):
         b = _Buf(H, W, C)

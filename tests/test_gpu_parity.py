@@ -247,6 +247,10 @@ BF16_CASES = [
     (2, 4, 4, 192, 64, 1, 1, 4, True, True, 0),
     (2, 3, 3, 384, 96, 1, 1, 8, True, True, 0),
     (2, 6, 6, 32, 48, 3, 1, 1, False, True, 5),
+    (2, 12, 12, 48, 48, 3, 1, 1, True, True, 0),      # flat-K kernel: Cin % 32 != 0 (unpadded 48-ch branch)
+    (2, 9, 9, 48, 96, 3, 2, 1, False, True, 0),       # flat-K, stride 2
+    (1, 6, 6, 48, 32, 1, 1, 1, False, False, 0),      # flat-K, 1x1, N tail
+    (2, 7, 7, 40, 48, 3, 1, 1, True, False, 0),       # flat-K, Cin = 40
 ]
 
 
