@@ -1,22 +1,22 @@
 #!/bin/bash
 # HBM traffic of the backbone's conv kernels from rocprofv3 PMC counters (separate passes for
 # FETCH_SIZE and WRITE_SIZE, counters only).  Writes <out>.json in the layout bench.py reads
-# (profiles/*_pmc_hbm_traffic*.json).   usage: tools/pmc_hbm_traffic.sh gpurun_out/pmc_hbm [dtype] [algo]
+# (profiles/*_pmc_hbm_traffic*.json).   usage: tools/pmc_hbm_traffic.sh gpurun_out/pmc_hbm [dtype] [algo] [batch]
 set -u
-OUT=$1; DT=${2:-f32}; ALGO=${3:-winograd}
+OUT=$1; DT=${2:-f32}; ALGO=${3:-winograd}; BATCH=${4:-64}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $grp | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d "$ROOT/$OUT/$tag" -- \
-      python "$ROOT/bench.py" --steps 2 --warmup 1 --single-stream --no-cpu-baseline --dtype $DT --algo $ALGO \
+      python "$ROOT/bench.py" --steps 2 --warmup 1 --single-stream --no-cpu-baseline --dtype $DT --algo $ALGO --batch $BATCH \
       > "$ROOT/$OUT/$tag.log" 2>&1
 done
 cd "$ROOT"
-python - "$OUT" "$DT" "$ALGO" <<'PY'
+python - "$OUT" "$DT" "$ALGO" "$BATCH" <<'PY'
 import csv, glob, json, sys, collections
-out, dt, algo = sys.argv[1], sys.argv[2], sys.argv[3]
+out, dt, algo, batch = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 FORWARDS = 3          # --steps 2 --warmup 1; every forward = 330 backbone convs + the SMPL-X GEMMs
 tot = collections.defaultdict(float)
 n = collections.defaultdict(int)
@@ -51,7 +51,7 @@ if 'FETCH_SIZE' in tot and 'WRITE_SIZE' in tot:
     rd = tot['FETCH_SIZE'] * 1024 / fw['FETCH_SIZE']
     wr = tot['WRITE_SIZE'] * 1024 / fw['WRITE_SIZE']
     res['hbm_bytes_per_backbone_forward'] = {'read_as_reported': rd, 'write': wr, 'as_reported': rd + wr,
-                                             'fetch_x2_corrected': 2 * rd + wr, 'batch': 64, 'size': 224,
+                                             'fetch_x2_corrected': 2 * rd + wr, 'batch': batch, 'size': 224,
                                              'dtype': dt, 'algo': algo}
 if 'SQ_VALU_MFMA_BUSY_CYCLES' in tot:
     res['mfma'] = {'SQ_VALU_MFMA_BUSY_CYCLES_sum': tot['SQ_VALU_MFMA_BUSY_CYCLES'],
