@@ -226,7 +226,7 @@ def run_measurements(args, rank, world):
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                      'frac_of_achievable_6290': achieved / 6290.0,
-                     'kernel': 'measure_scan_lds_kernel + measure_hull_wave_kernel (one launch '
+                     'kernel': 'measure_scan2_kernel + measure_hull2_kernel (one launch '
                                'group = both kernels; the time is the whole group)',
                      'bytes_per_launch_group': nbytes, 'ms_per_launch_group': ms},
     }
