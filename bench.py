@@ -320,10 +320,14 @@ def run_regressor(args, rank, world, local_rank):
     x_np = syn.synthetic_images(B, args.size, 100 + rank)
     x = torch.from_numpy(x_np).cuda()
     gatherer = parallel.BetasGatherer(world)
+    # the timed region includes the D2H of the betas (async copy into pinned host
+    # memory on the compute stream; the closing synchronize covers the last one)
+    betas_host = torch.empty(B, 10, dtype=torch.float32).pin_memory()
 
     def step():
         with torch.no_grad():
             out = net(x, None)
+            betas_host.copy_(out['stage_02']['betas'], non_blocking=True)
             betas = gatherer(out['stage_02']['betas'])     # joined at the next call / wait()
         return out, betas
 
@@ -362,6 +366,7 @@ def run_regressor(args, rank, world, local_rank):
         dist.all_gather(allr, own)
         per_rank = [float(t.item()) for t in allr]
     assert betas.shape == (world * B, 10)
+    assert torch.equal(betas_host, out['stage_02']['betas'].cpu())      # the D2H copy landed
     if world > 1:      # the gathered tensor really holds every rank's betas: own shard in place
         assert torch.equal(betas[rank * B:(rank + 1) * B], out['stage_02']['betas'])
 
@@ -408,6 +413,7 @@ def run_regressor(args, rank, world, local_rank):
                                            'configs[2] precision)'}[args.dtype],
                    'global_batch': world * B, 'parallelism': f'dp{world}',
                    'multi_stream': not args.single_stream, 'conv_algo': algo,
+                   'd2h_betas_in_timed_region': True,
                    'hip_graph': bool(net.backbone.use_graph is True or
                                      (net.backbone.use_graph == 'auto' and
                                       B <= net.backbone.graph_max_batch))},

@@ -94,9 +94,14 @@ typedef struct ShapyConv {
   int32_t out_ld, out_coff, res_ld, res_coff;
   int32_t relu;       /* 1: ReLU after the (residual) add                                  */
   int32_t ups;        /* 1 = none; 2/4/8 = nearest-upsample scatter                        */
-  int32_t tile;       /* 0 = choose automatically; else a SHAPY_TILE_* id (bench/tuning)   */
+  int32_t tile;       /* 0 = choose automatically; low byte: a SHAPY_TILE_* id; higher bits are
+                         A/B knobs of tools/conv_bench.py (shapy_amd/_lib.py: TILES), e.g. 0x2000
+                         never Winograd, 0x4000 / 0x8000 Winograd tile groups, 0x20000 Winograd K
+                         loop chunk by chunk, 0x40000 / 0x80000 three / one chunk(s) of loads in
+                         flight.  Speed only: every setting computes the same convolution.      */
   int32_t dtype;      /* storage type of in / wgt / res / out: SHAPY_DTYPE_F32 (f32 MFMA, exact
-                         f32) or SHAPY_DTYPE_BF16 (bf16 MFMA, f32 accumulate; Cin % 32 == 0)  */
+                         f32) or SHAPY_DTYPE_BF16 (bf16 MFMA, f32 accumulate; Cin % 8 == 0, and
+                         Cin >= 32 with ups == 1 when Cin % 32 != 0: the flat-K kernel)          */
   int32_t reserved0;
   const void *wgt_wino; /* NULL, or the Winograd F(2x2,3x3) transform of wgt for a float32
                          3x3 / stride 1 / pad 1 layer: U[p = 4i+j][Cin/16][Cout][16] float32,

@@ -47,7 +47,6 @@ struct ConvK {
   int flat;                     // bf16, Cin % 32 != 0: flat-K kernel
   int pd3;                      // implicit GEMM: three chunks of global loads in flight
   int dbg;                      // -DSHAPY_WINO_TIMING builds only: ablation mask (wrong results)
-  int stagger_us, stagger_slots;  // Winograd: start delay per resident-workgroup slot (conv_wino.hip)
 };
 
 // Winograd F(2x2,3x3) path of the float32 3x3 / stride-1 layers (conv_wino.hip)

@@ -358,7 +358,6 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   // three chunks of global loads in flight: bf16 always (its chunks are 50-100 ns of MFMAs);
   // float32 on request (tile flag 0x40000, A/B benches)
   k.pd3 = (bf16 || (d.tile & 0x40000)) && !(d.tile & 0x80000) ? 1 : 0;
-  k.stagger_us = 0; k.stagger_slots = 0;
   if (d.dtype == SHAPY_DTYPE_F32 && !(d.tile & 0x2000) && conv_wino_eligible(k))
     return conv2d_wino(k, (d.tile & 0x4000) ? 1 : (d.tile & 0x8000) ? 2 : 0, s);
   // d.tile: low byte = SHAPY_TILE_* (0 = auto).  Tuning knobs of tools/conv_bench.py:

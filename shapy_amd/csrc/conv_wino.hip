@@ -75,17 +75,6 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
   __shared__ __attribute__((aligned(16))) char lds[NVB * LDS_V > LDS_X ? NVB * LDS_V : LDS_X];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // De-synchronise the workgroups that share a CU.  All workgroups of a launch have the same
-  // duration, so the 2-3 resident ones run in lockstep for the whole launch: all in their
-  // prologue (matrix cores idle), all in the K loop (contending for them), all in the epilogue
-  // (idle again).  Delaying the k-th resident workgroup of the FIRST generation by k / occupancy
-  // of a workgroup lifetime staggers every later generation too (a finished workgroup is replaced
-  // at once).  Placement heuristic only (block b -> CU b mod 256 in the first generation); a
-  // different dispatch order changes the speed, never the result.
-  if (p.stagger_us > 0 && blockIdx.x < 256 * p.stagger_slots) {
-    const int n = (blockIdx.x >> 8) * p.stagger_us;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);        // 32 x 64 cycles ~ 1 us
-  }
   WINO_STAMP(0);
   const int wg = conv_tile_index(p);
   const int m_blk = (wg / p.nbx) * MT, n_blk = (wg % p.nbx) * N;
@@ -404,17 +393,6 @@ int conv2d_wino(ConvK k, int tm, hipStream_t s) {
 #endif
   // transformed filters larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
   if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt2_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
-  {
-    // expected lifetime of a workgroup (phase timing, tools/wino_timing.py): ~7 us of prologue,
-    // accumulator exchange and epilogue + ~2.3 us per chunk and tile group
-    static const int env = getenv("SHAPY_WINO_STAGGER") ? atoi(getenv("SHAPY_WINO_STAGGER")) : -1;
-    const int occ = (nn == 4 || tm == 2) ? 2 : 3;
-    const float life = 7.f + 2.3f * (k.Cin / 16) * tm;
-    k.stagger_slots = occ;
-    k.stagger_us = env >= 0 ? env : 0;
-    if (env == -2) k.stagger_us = (int)(life / occ + 0.5f);
-    if ((long)k.nbx * k.nby < 512 * occ) k.stagger_us = 0;          // not even two generations
-  }
   // all-K staging (no barriers / patch waits inside the K loop) where the whole K extent fits the
   // exchange buffer: Cin = 48 with 48-wide N tiles, Cin = 64 with 64-wide ones (tile flag
   // 0x20000 keeps the generic loop: A/B benches)

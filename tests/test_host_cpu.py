@@ -362,3 +362,20 @@ def test_f32x6_plan_packs_the_same_weights_as_planes(hrnet):
         assert np.array_equal(bf, bx)
         checked += 1
     assert checked == 12
+
+
+def test_bf16_plan_keeps_the_48_channel_branch_unpadded():
+    """bf16 rows are addressed in 8-channel (16-byte) slots; the 48-channel branch is NOT padded to
+    64 channels any more (csrc/conv_igemm.hip: flat-K kernel for Cin % 32 != 0)."""
+    import __graft_entry__ as ge
+    net, _ = ge.make_network(model_folder='/tmp/shapy_synth_models', device='cpu')
+    plan = net.backbone._build_plan(64, 64, bf16=True)
+    convs = [o for o in plan.ops if o['type'] == 0]
+    assert any(o['Cin'] == 48 and o['Cout'] == 48 and o['ksize'] == 3 for o in convs)
+    for o in convs:
+        assert o['Cin'] % 8 == 0 and o['Cout'] % 8 == 0 and o['in_ld'] % 8 == 0
+        if o['Cin'] % 32:                      # flat-K kernel: no upsample epilogue, Cin >= 32
+            assert o['ups'] == 1 and o['Cin'] >= 32, o
+    f32 = net.backbone._build_plan(64, 64)
+    assert [(o['Cin'], o['Cout']) for o in convs] == \
+        [(o['Cin'], o['Cout']) for o in f32.ops if o['type'] == 0]
