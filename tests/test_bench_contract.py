@@ -9,7 +9,7 @@ ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
 
 
 @pytest.mark.parametrize('name', ['r01_bench_f32.json', 'r01_bench_f32x6.json', 'r01_bench_bf16.json',
-                                  'r02u_bench_f32_winograd_default.json'])
+                                  'r02v_bench_f32_winograd_default.json'])
 def test_committed_bench_line_has_the_contract_fields(name):
     with open(osp.join(ROOT, 'profiles', name)) as f:
         r = json.loads(f.read().strip().splitlines()[-1])
