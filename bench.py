@@ -151,6 +151,13 @@ def self_spawn(n):
     return subprocess.call(cmd, env=env)
 
 
+def barrier():
+    """RCCL barrier on this rank's own GPU (named explicitly: no device guessing)."""
+    import torch
+    import torch.distributed as dist
+    dist.barrier(device_ids=[torch.cuda.current_device()])
+
+
 def hip_events(n):
     import torch
     return ([torch.cuda.Event(enable_timing=True) for _ in range(n)],
@@ -191,7 +198,7 @@ def run_measurements(args, rank, world):
     ev0, ev1 = hip_events(args.steps)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -200,7 +207,7 @@ def run_measurements(args, rank, world):
         ev1[i].record()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -315,6 +322,8 @@ def run_regressor(args, rank, world, local_rank):
     net.backbone.use_graph = {'auto': 'auto', 'on': True, 'off': False}[args.graph]
     if args.algo:
         net.backbone.conv_algo = args.algo
+    if args.wino4_min_hw:
+        net.backbone.wino4_min_hw = args.wino4_min_hw
     B = args.batch
     # distinct synthetic images per rank (global batch = world * B), resident in HBM
     x_np = syn.synthetic_images(B, args.size, 100 + rank)
@@ -342,7 +351,7 @@ def run_regressor(args, rank, world, local_rank):
 
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -352,7 +361,7 @@ def run_regressor(args, rank, world, local_rank):
     torch.cuda.synchronize()
     own_dt = time.perf_counter() - t0
     if world > 1:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     h0.remove(); h1.remove()
@@ -382,7 +391,11 @@ def run_regressor(args, rank, world, local_rank):
               'f32x6': 'conv_x6_kernel (6 x v_mfma_f32_16x16x32_bf16 per f32 product; peak = '
                        'dense bf16 peak / 6)'}[args.dtype]
     algo = getattr(net.backbone, 'conv_algo', 'direct')
-    if args.dtype == 'f32' and algo != 'direct':
+    if args.dtype == 'f32' and algo == 'winograd4':
+        kernel += f' + conv_wino4_kernel (Winograd F(4x4,3x3), maps >= {net.backbone.wino4_min_hw} ' \
+                  'px) + conv_wino_kernel (F(2x2,3x3), the other 3x3 stride-1 layers); achieved ' \
+                  'counts the ALGORITHMIC direct-conv FLOPs'
+    elif args.dtype == 'f32' and algo != 'direct':
         kernel += f' + conv_wino_kernel (Winograd F(2x2,3x3) for the 3x3 stride-1 layers, ' \
                   f'algo={algo}; achieved counts the ALGORITHMIC direct-conv FLOPs)'
     # HBM bytes per launch group (one backbone forward) from the committed PMC passes, gfx950
@@ -460,8 +473,11 @@ def main():
                     help='f32 = BASELINE configs[1] (headline) on the f32 matrix-core path; '
                          'f32x6 = same float32 tensors, products from the exact 3-way bf16 split '
                          '(6 bf16 MFMAs per product); bf16 = configs[2] storage type')
-    ap.add_argument('--algo', default=None, choices=['direct', 'auto', 'winograd'],
+    ap.add_argument('--algo', default=None, choices=['direct', 'auto', 'winograd', 'winograd4'],
                     help='f32 conv algorithm override (default: the backbone\'s own default)')
+    ap.add_argument('--wino4-min-hw', type=int, default=0,
+                    help='--algo winograd4: smallest map side that takes F(4x4,3x3) (default: the '
+                         'backbone\'s own, 28)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -485,7 +501,7 @@ def main():
         from shapy_amd import build as hip_build      # fresh checkout: the library is git-ignored
         hip_build.build()
     if world > 1:
-        dist.barrier()
+        barrier()
 
     if args.workload == 'measurements':
         res = run_measurements(args, rank, world)
@@ -496,7 +512,7 @@ def main():
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 

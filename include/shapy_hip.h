@@ -98,7 +98,9 @@ typedef struct ShapyConv {
                          A/B knobs of tools/conv_bench.py (shapy_amd/_lib.py: TILES), e.g. 0x2000
                          never Winograd, 0x4000 / 0x8000 Winograd tile groups, 0x20000 Winograd K
                          loop chunk by chunk, 0x40000 / 0x80000 three / one chunk(s) of loads in
-                         flight.  Speed only: every setting computes the same convolution.      */
+                         flight.  Speed only: every setting computes the same convolution.
+                         One bit describes DATA instead: SHAPY_TILE_WINO4 (0x100000) says that
+                         wgt_wino holds F(4x4,3x3) filters (below).                             */
   int32_t dtype;      /* storage type of in / wgt / res / out: SHAPY_DTYPE_F32 (f32 MFMA, exact
                          f32) or SHAPY_DTYPE_BF16 (bf16 MFMA, f32 accumulate; Cin % 8 == 0, and
                          Cin >= 32 with ups == 1 when Cin % 32 != 0: the flat-K kernel)          */
@@ -108,8 +110,14 @@ typedef struct ShapyConv {
                          U[i][j] = (G g G^T)[i][j] (shapy_amd/utils/winograd.py).  When given
                          (and Cin % 16 == 0, Cout % 48 == 0 or % 64 == 0, 16-byte aligned out / res / bias
                          rows) the layer runs on csrc/conv_wino.hip: 2.25x fewer MFMAs, result
-                         equal to the direct sum up to float32 rounding of the transforms.   */
+                         equal to the direct sum up to float32 rounding of the transforms.
+                         With SHAPY_TILE_WINO4 set in `tile`: the F(4x4,3x3) transform instead,
+                         U[p = 6i+j][Cin/16][Cout][16] with the 6x3 G of the points {0, +-1, +-2,
+                         inf} (winograd.transform_filters4); needs Cout % 48 == 0 and tensors of
+                         at most 1 GiB; runs on csrc/conv_wino4.hip (4x fewer MFMAs than the
+                         direct sum); SHAPY_EINVAL when the layer does not qualify.           */
 } ShapyConv;
+#define SHAPY_TILE_WINO4 0x100000
 
 int shapy_conv2d(const ShapyConv *desc_host, void *stream);
 

@@ -20,6 +20,7 @@ SOURCES = {
     'conv_igemm.hip': [],
     'conv_x6.hip': [],
     'conv_wino.hip': [],
+    'conv_wino4.hip': [],
     'hrnet_ops.hip': [],
     'body.hip': [],
     # bit-identical float32 decisions with the CPU oracle: no FMA contraction here

@@ -358,6 +358,13 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   // three chunks of global loads in flight: bf16 always (its chunks are 50-100 ns of MFMAs);
   // float32 on request (tile flag 0x40000, A/B benches)
   k.pd3 = (bf16 || (d.tile & 0x40000)) && !(d.tile & 0x80000) ? 1 : 0;
+  // tile flag 0x100000: wgt_wino holds F(4x4,3x3) filters [36][Cin/16][Cout][16] (conv_wino4.hip;
+  // the host's policy again: HighResolutionNet.conv_algo = 'winograd4') -- there is no other
+  // kernel for that layout, so an ineligible layer is an error, not a fallback
+  if (d.tile & 0x100000) {
+    if (d.dtype != SHAPY_DTYPE_F32 || !conv_wino_eligible(k) || k.Cout % 48) return SHAPY_EINVAL;
+    return conv2d_wino4(k, s);
+  }
   if (d.dtype == SHAPY_DTYPE_F32 && !(d.tile & 0x2000) && conv_wino_eligible(k))
     return conv2d_wino(k, (d.tile & 0x4000) ? 1 : (d.tile & 0x8000) ? 2 : 0, s);
   // d.tile: low byte = SHAPY_TILE_* (0 = auto).  Tuning knobs of tools/conv_bench.py:

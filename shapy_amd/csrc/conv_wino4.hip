@@ -1,0 +1,343 @@
+// Winograd F(4x4, 3x3) convolution on the f32 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+// Same layers as conv_wino.hip (3x3 / stride 1 / pad 1: both convs of every BasicBlock of
+// regressor/human_shape/models/backbone/hrnet.py:175-193), one step further down the
+// minimal-filtering ladder:
+//     Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A,     d: 6x6 input patch, Y: 4x4 outputs
+// 36 multiplies per 16 outputs and channel pair = 2.25 per output (direct: 9, F(2x2,3x3): 4), and a
+// patch overlap of 36/16 = 2.25 loads per output pixel instead of 4.  Interpolation points
+// {0, +-1, +-2, inf} (Lavin & Gray); filter transform in float64 on the host.  Measured on the CPU
+// through the whole HRNet-W48 in float32 (tools/wino4_emulate.py --network): features within
+// 1.8e-6 of float64, the same as the direct float32 convolution.
+//
+// GEMM view: 36 independent GEMMs (Winograd position p = 6 i + j), [tiles x Cin] x [Cin x Cout].
+// One 256-thread workgroup = 16 consecutive tiles (4x4 output pixels each, row-major over
+// (b, ty, tx)) x N = 48 or 64 output channels:
+//   * staging, all four waves: thread (tile, channel) loads the 36 pixels of its patch as scalars
+//     (16 consecutive lanes = 64 contiguous bytes; out-of-image taps zeroed by the buffer bounds
+//     check), applies B^T d B entirely in registers -- no cross-lane exchange -- and writes
+//     V[p][tile][16 ch] to LDS (36 KB per 16-channel chunk; 16-byte slots XOR-swizzled by the
+//     tile so that the fragment reads are conflict-free; a wave's 4-byte writes of one position
+//     cover 256 contiguous bytes).  Two V buffers, one barrier per chunk; the next chunk's patch
+//     is in flight in registers while this one is multiplied.
+//   * multiply, wave w < N/16: ALL 36 positions of ONE 16-channel tile (144 accumulator
+//     registers).  A fragments from LDS (one ds_read_b128 = the k-operands of 4 MFMAs), B
+//     fragments straight from the transformed filters in global memory, layout
+//     [p][Cin/16][Cout][16] (1 KB contiguous per wave load), a ring of WINO4_RING positions ahead.
+//     Because a wave owns every position of its (tile, channel) outputs, the output transform
+//     A^T M A happens in registers: no accumulator exchange through LDS (conv_wino.hip spends
+//     53 KB of LDS and two barriers on it).
+//   * epilogue: per lane 4 tiles x 16 pixels of one channel: bias, residual, ReLU, 4-byte
+//     stores (16 lanes = 64 contiguous bytes; the N/16 waves of the workgroup cover the pixel's
+//     whole 192- / 256-byte row).
+// With N = 48 the fourth wave only stages: the register budget (256 per lane) allows two waves
+// per SIMD either way, so the idle slot costs no occupancy.
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace shapy {
+
+#ifndef WINO4_RING
+#define WINO4_RING 12         // B-fragment positions in flight per multiplying wave (divides 36)
+#endif
+
+// one application of B^T (6 x 6) to a 6-vector (of 4 channels)
+__device__ __forceinline__ void wino4_bt(const f32x4 (&d)[6], f32x4 (&o)[6]) {
+  const f32x4 a = d[4] - 4.f * d[2];
+  const f32x4 b = d[3] - 4.f * d[1];
+  const f32x4 c = d[4] - d[2];
+  const f32x4 e = d[3] - d[1];
+  o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+  o[1] = a + b;
+  o[2] = a - b;
+  o[3] = c + 2.f * e;
+  o[4] = c - 2.f * e;
+  o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+
+// one application of A^T (4 x 6) to a 6-vector
+__device__ __forceinline__ void wino4_at(const float (&m)[6], float (&o)[4]) {
+  const float s12 = m[1] + m[2], d12 = m[1] - m[2];
+  const float s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = (m[0] + s12) + s34;
+  o[1] = fmaf(2.f, d34, d12);
+  o[2] = fmaf(4.f, s34, s12);
+  o[3] = fmaf(8.f, d34, d12) + m[5];
+}
+
+// Workgroup barrier WITHOUT the fence of __syncthreads(): only LDS traffic is ordered across it
+// (the staging wave's ds_writes, the multiplying waves' ds_reads).  The fence would also drain
+// vmcnt, i.e. make every wave wait for its prefetched global loads (filter ring, next patch) at
+// every chunk boundary.
+__device__ __forceinline__ void wino4_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// 256 threads = three multiplying waves (16 output channels each, N = 48 per workgroup) + one
+// staging wave.  KC > 0: the layer has exactly KC chunks (Cin = 16 KC) and the multiplying waves'
+// chunk loop is unrolled: hipcc's s_waitcnt bookkeeping is exact only in straight-line code -- at
+// the header of a real loop it drains vmcnt(0), i.e. waits for the whole filter ring once per
+// chunk (an L2 latency of idle matrix cores every 144 MFMAs).
+template <int KC>
+__global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
+  constexpr int N = 48;
+  constexpr int PSTR = 1024;                          // bytes per position: 16 tiles x 16 ch f32
+  constexpr int LDS_V = 36 * PSTR;
+  constexpr int R = WINO4_RING;
+  constexpr int BAD = 0x40000000;                     // >= num_records of every buffer used here
+  static_assert(36 % R == 0 && R >= 2, "position q lives in ring slot q % R in every chunk");
+  __shared__ __attribute__((aligned(16))) char lds[2 * LDS_V];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // wave-uniform: scalar branches
+  const int wg = conv_tile_index(p);
+  const int m_blk = (wg / p.nbx) * 16, n_blk = (wg % p.nbx) * N;
+  const int H = p.Hi, W = p.Wi;
+  const int TW = (W + 3) >> 2, TH = (H + 3) >> 2;
+  const int T = p.wino_tiles;
+  const int CC = p.Cin >> 4;
+
+  if (wave == 3) {
+    // =========================== staging wave ===========================
+    // lane (tile, c4): the 6 x 6 patch of one tile for 4 channels of the current 16-channel
+    // chunk: 36 buffer_load_dwordx4 (144 registers -- this wave holds no accumulators).  Zero
+    // padding by the buffer bounds check: an out-of-image row / column adds 0x40000000 to the
+    // byte offset, so any offset with an invalid part lies in [1 GiB, 4 GiB) >= num_records
+    // (the launcher keeps in_bytes <= 1 GiB) -- no select, no branch.
+    const __amdgpu_buffer_rsrc_t rs_in =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
+    const int tile_s = lane >> 2, c4 = lane & 3;
+    int row_off[6], col_off[6];
+    {
+      const int pix_stride = p.in_ld * 4;
+      const int tile = m_blk + tile_s;
+      const bool live = tile < T;
+      const int tt = live ? tile : 0;
+      const int tx = tt % TW;
+      const int tq = tt / TW;
+      const int ty = tq % TH;
+      const int b = tq / TH;
+      const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const bool ok = live & ((unsigned)(y0 + i) < (unsigned)H);
+        row_off[i] = ok ? (b * H + y0 + i) * W * pix_stride + c4 * 16 : BAD;
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        col_off[j] = (unsigned)(x0 + j) < (unsigned)W ? (x0 + j) * pix_stride : BAD;
+    }
+    // LDS image V[p][tile][16 ch]: 16-byte slot c4 of row `tile` sits at slot c4 ^ f(tile),
+    // f(r) = (r ^ r >> 1) & 3 -- the layout of conv_igemm.hip's staging buffer (conflict-free
+    // ds_write_b128 and ds_read_b128, tools/lds_swizzle_check.py)
+    const int st_off = tile_s * 64 + (((c4 ^ tile_s ^ (tile_s >> 1)) & 3) << 4);
+
+    f32x4 raw[6][6];
+    auto gload_col = [&](int j, int c0) {              // column j of the patch, channels c0 ..
+      // (the asm keeps the chunk offset inside the sum: hipcc otherwise hoists the 36
+      // loop-invariant row + column sums out of the K loop and spills them to scratch)
+      int co = col_off[j] + c0 * 4;
+      asm volatile("" : "+v"(co));
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        raw[i][j] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, row_off[i] + co, 0, 0));
+    };
+#pragma unroll
+    for (int j = 0; j < 6; ++j) gload_col(j, 0);
+    for (int cc = 0; cc < CC; ++cc) {
+      // chunk cc -> V buffer cc & 1.  That buffer was last read by the multiply of chunk
+      // cc - 2, which every wave left through the barrier this wave passed at the end of the
+      // previous iteration.
+      const bool more = cc + 1 < CC;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {                                // T = d B  (along x)
+        f32x4 o[6];
+        wino4_bt(raw[i], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) raw[i][j] = o[j];
+        __builtin_amdgcn_sched_barrier(0);     // (row by row: bounds the live temporaries)
+      }
+      char *Vb = lds + (cc & 1) * LDS_V + st_off;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {                                // V = B^T T  (along y)
+        const f32x4 colv[6] = {raw[0][j], raw[1][j], raw[2][j], raw[3][j], raw[4][j], raw[5][j]};
+        f32x4 v[6];
+        wino4_bt(colv, v);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4 *>(Vb + (6 * i + j) * PSTR) = v[i];
+        // the column's registers are free again: request the same column of the NEXT chunk, which
+        // then has a whole multiply phase to arrive
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) gload_col(j, (cc + 1) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wino4_lds_barrier();                   // chunk cc is staged (barrier #cc of CC + 1)
+    }
+    wino4_lds_barrier();                     // pairs with the multiplying waves' last barrier
+    return;
+  }
+
+  // =========================== multiplying waves ===========================
+  // wave w owns output channels n_blk + 16 w .. + 15 for ALL 36 positions
+  const __amdgpu_buffer_rsrc_t rs_u =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt2), 0, p.wgt2_bytes, 0x00020000);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int frag_off = l15 * 64 + (((g ^ l15 ^ (l15 >> 1)) & 3) << 4);
+  const int n0 = n_blk + 16 * wave;
+  const int u_lane = ((n0 + l15) * 16 + 4 * g) * 4;
+  const int u_pos = CC * p.Cout * 64, u_chunk = p.Cout * 64;
+
+  // B-fragment loads: the per-lane part of the address is ONE register (u_lane); position and
+  // chunk go into the scalar offset of the buffer instruction (as a vector offset hipcc keeps 36
+  // strength-reduced address registers alive across the K loop)
+  u32x4 bring[R];
+  auto bload = [&](int slot, int pos, int cc, bool live) {
+    bring[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, live ? u_lane : BAD,
+                                                        pos * u_pos + cc * u_chunk, 0);
+  };
+
+  f32x4 acc[36];
+#pragma unroll
+  for (int q = 0; q < 36; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < R; ++q) bload(q, q, 0, true);
+
+  auto chunk = [&](int cc, bool more) {
+    wino4_lds_barrier();                     // chunk cc is staged
+    const char *Vb = lds + (cc & 1) * LDS_V + frag_off;
+    u32x4 af[2][2];
+    af[0][0] = *reinterpret_cast<const u32x4 *>(Vb + 0 * PSTR);
+    af[0][1] = *reinterpret_cast<const u32x4 *>(Vb + 1 * PSTR);
+#pragma unroll
+    for (int pp = 0; pp < 36; pp += 2) {
+      const int cur = (pp >> 1) & 1;
+      if (pp + 2 < 36) {
+        af[cur ^ 1][0] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 2) * PSTR);
+        af[cur ^ 1][1] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 3) * PSTR);
+      }
+      // two positions interleaved: consecutive MFMAs hit different accumulators (40-cycle
+      // dependent latency vs a 32-cycle issue interval)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+            __uint_as_float(af[cur][0][kk]), __uint_as_float(bring[pp % R][kk]), acc[pp], 0, 0, 0);
+        acc[pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+            __uint_as_float(af[cur][1][kk]), __uint_as_float(bring[(pp + 1) % R][kk]), acc[pp + 1],
+            0, 0, 0);
+      }
+      // refill the two ring slots just consumed, R positions ahead (pinned here: the compiler
+      // otherwise sinks the loads to the end of the chunk)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int q = pp + e + R;
+        if (q < 36) bload((pp + e) % R, q, cc, true);
+        else bload((pp + e) % R, q - 36, cc + 1, more);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if constexpr (KC > 0) {
+#pragma unroll
+    for (int cc = 0; cc < KC; ++cc) chunk(cc, cc + 1 < KC);
+  } else {
+    for (int cc = 0; cc < CC; ++cc) chunk(cc, cc + 1 < CC);
+  }
+  wino4_lds_barrier();                       // barrier #CC: the staging wave's closing one
+
+  // ---- epilogue: output transform in registers, bias + residual + ReLU, store ----
+  // Per lane: channel `col`, tiles 4 g + r (MFMA C layout), 16 pixels each.  Residual loads and
+  // stores are buffer instructions: per-lane part of the address = the tile's first pixel (one
+  // register per tile), pixel offset inside the tile = scalar offset; pixels outside the image
+  // (partial edge tiles) and dead tiles get the out-of-range offset, which drops the access.
+  const int col = n0 + l15;
+  const float bias = p.bias ? p.bias[col] : 0.f;
+  const __amdgpu_buffer_rsrc_t rs_out =
+      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, BAD, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(p.res ? p.res : p.in), 0, BAD, 0x00020000);
+  const bool has_res = p.res != nullptr;
+  int obase[4], rbase[4], nrow[4], ncol[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int tile = m_blk + 4 * g + r;
+    const bool live = tile < T;
+    const int tt = live ? tile : 0;
+    const int tx = tt % TW;
+    const int tq = tt / TW;
+    const int ty = tq % TH;
+    const int b = tq / TH;
+    const int pix0 = (b * H + 4 * ty) * W + 4 * tx;
+    obase[r] = live ? (pix0 * p.out_ld + p.out_coff + col) * 4 : BAD;
+    rbase[r] = (live & has_res) ? (pix0 * p.res_ld + p.res_coff + col) * 4 : BAD;
+    nrow[r] = H - 4 * ty;           // >= 4 for a full tile
+    ncol[r] = W - 4 * tx;
+  }
+  float resv[2][16];
+  auto rload = [&](int r, float (&rv)[16]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const bool ok = (a < nrow[r]) & (bb < ncol[r]);
+        rv[4 * a + bb] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+            rs_res, ok ? rbase[r] : BAD, (a * W + bb) * p.res_ld * 4, 0));
+      }
+  };
+  rload(0, resv[0]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (r + 1 < 4) rload(r + 1, resv[(r + 1) & 1]);
+    float s[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const float m[6] = {acc[6 * i + 0][r], acc[6 * i + 1][r], acc[6 * i + 2][r],
+                          acc[6 * i + 3][r], acc[6 * i + 4][r], acc[6 * i + 5][r]};
+      wino4_at(m, s[i]);                                          // M A   (along x)
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      const float colv[6] = {s[0][bb], s[1][bb], s[2][bb], s[3][bb], s[4][bb], s[5][bb]};
+      float y[4];
+      wino4_at(colv, y);                                          // A^T (M A)   (along y)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const bool ok = (a < nrow[r]) & (bb < ncol[r]);
+        float v = (y[a] + bias) + resv[r & 1][4 * a + bb];
+        if (p.relu) v = fmaxf(v, 0.f);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, ok ? obase[r] : BAD,
+                                              (a * W + bb) * p.out_ld * 4, 0);
+      }
+    }
+  }
+}
+
+// tile flag 0x100000 of ShapyConv.tile: wgt_wino holds F(4x4,3x3) filters [36][Cin/16][Cout][16]
+int conv2d_wino4(ConvK k, hipStream_t s) {
+  const int B = k.M / (k.Ho * k.Wo);
+  k.wino_tiles = B * ((k.Hi + 3) / 4) * ((k.Wi + 3) / 4);
+  const unsigned long long wb = 144ull * k.Cin * k.Cout;       // 36 positions x f32
+  if (wb >= 0x7fffffffull) return SHAPY_EINVAL;
+  k.wgt2_bytes = (unsigned)wb;
+  // 0x40000000 doubles as the "out of range" byte offset of every buffer access in the kernel
+  const unsigned long long lim = 0x40000000ull;
+  if (k.Cout % 48 || k.in_bytes > lim || 4ull * k.M * k.out_ld > lim ||
+      (k.res && 4ull * k.M * k.res_ld > lim))
+    return SHAPY_EINVAL;
+  k.nbx = k.Cout / 48;
+  k.nby = (k.wino_tiles + 15) / 16;
+  // transformed filters larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
+  if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt2_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
+  const dim3 grid(k.nbx * k.nby), blk(256);
+  if (k.Cin == 48)
+    hipLaunchKernelGGL(conv_wino4_kernel<3>, grid, blk, 0, s, k);
+  else if (k.Cin == 96)
+    hipLaunchKernelGGL(conv_wino4_kernel<6>, grid, blk, 0, s, k);
+  else
+    hipLaunchKernelGGL(conv_wino4_kernel<0>, grid, blk, 0, s, k);
+  return (int)hipGetLastError();
+}
+
+}  // namespace shapy

@@ -349,8 +349,12 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: eligible HRNet class incl. the 7x7 maps (profiles/conv_bench_r02*); 'direct' =
         #: implicit GEMM for every layer (the exact-f32 fmaf chain of the reference's sum
         #: order); 'auto' = Winograd only on maps of at least wino_min_hw pixels a side
+        #: 'winograd4' = F(4x4,3x3) (csrc/conv_wino4.hip: 36 instead of 64 multiplies per 4x4
+        #: outputs, 48-channel N tiles) on maps of at least wino4_min_hw pixels a side --
+        #: smaller maps have too few 4x4 tiles to fill the chip --, F(2x2,3x3) on the rest
         self.conv_algo = 'winograd'
         self.wino_min_hw = 14
+        self.wino4_min_hw = 28
         self._engine_ver = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
 
@@ -468,12 +472,16 @@ class HighResolutionNet(VersionedWeights, nn.Module):
     def _use_wino(self, ks, st, pad, cin, cout, Hi, Wi, ups):
         if self.conv_algo == 'direct' or not winograd.eligible(ks, st, pad, cin, cout, ups):
             return False
-        return self.conv_algo == 'winograd' or min(Hi, Wi) >= self.wino_min_hw
+        return self.conv_algo in ('winograd', 'winograd4') or min(Hi, Wi) >= self.wino_min_hw
+
+    def _use_wino4(self, ks, st, pad, cin, cout, Hi, Wi, ups):
+        return (self.conv_algo == 'winograd4' and min(Hi, Wi) >= self.wino4_min_hw
+                and winograd.eligible4(ks, st, pad, cin, cout, ups))
 
     def _build_plan(self, H, W, bf16=False, x6=False):
         P = _Plan(bf16, x6)
         ov = self.tile_overrides
-        if self.conv_algo not in ('direct', 'winograd', 'auto'):
+        if self.conv_algo not in ('direct', 'winograd', 'winograd4', 'auto'):
             raise ValueError(f'unknown conv_algo {self.conv_algo!r}')
 
         def conv(conv_m, bn, inb, Hi, Wi, outb=None, res=None, relu=False, ups=1, lane=0,
@@ -492,14 +500,18 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 w, b = wp, bp
             if outb is None:
                 outb = P.buf(Ho * ups, Wo * ups, cout_p)
-            wino_off = -1
-            if not (bf16 or x6) and self._use_wino(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
+            wino_off, wino_flag = -1, 0
+            if not (bf16 or x6) and self._use_wino4(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
+                wino_off = P.add_weights(winograd.transform_filters4(w))
+                wino_flag = _lib.TILE_WINO4
+            elif not (bf16 or x6) and self._use_wino(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
                 wino_off = P.add_weights(winograd.transform_filters(w))
             P.op(type=_lib.OP_CONV, lane=lane, inb=inb, outb=outb, resb=res, Hi=Hi, Wi=Wi, Cin=cin_p,
                  in_ld=inb.C, Ho=Ho, Wo=Wo, Cout=cout_p, ksize=ks, stride=st, pad=pad,
                  out_ld=out_ld or outb.C, out_coff=out_coff,
                  res_ld=(res_ld or (res.C if res is not None else 0)), res_coff=res_coff,
-                 relu=int(relu), ups=ups, tile=_lib.TILES[ov.get(name, 'auto')] | self.tile_flags,
+                 relu=int(relu), ups=ups,
+                 tile=_lib.TILES[ov.get(name, 'auto')] | self.tile_flags | wino_flag,
                  wgt_off=P.add_conv_weights(w), bias_off=P.add_weights(b), wino_off=wino_off)
             return outb, Ho, Wo
 
@@ -657,7 +669,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             self._engine = {}
             self._engine_ver = ver
         key = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
-               self.tile_flags, tuple(sorted(self.tile_overrides.items())))
+               self.wino4_min_hw, self.tile_flags, tuple(sorted(self.tile_overrides.items())))
         eng = self._engine.get(key)
         if eng is not None:
             return eng

@@ -59,3 +59,57 @@ def conv_reference(x_nhwc, u, bias=None):
     if bias is not None:
         y = y + np.asarray(bias, f32)
     return y.astype(f32)
+
+
+# ---- F(4x4, 3x3): csrc/conv_wino4.hip --------------------------------------------------------
+# Interpolation points {0, 1, -1, 2, -2, inf} (Lavin & Gray): 36 multiplies per 4x4 output tile.
+G4 = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
+               [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1.0]])
+BT4 = np.array([[4.0, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0],
+                [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]])
+AT4 = np.array([[1.0, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0],
+                [0, 1, -1, 8, -8, 1]])
+
+
+def eligible4(ksize, stride, pad, cin, cout, ups=1):
+    """Layers conv_wino4.hip takes: 3x3 / stride 1 / pad 1, 16-channel K chunks, 48-channel N
+    tiles (three multiplying waves of 16 channels + one staging wave per workgroup)."""
+    return (ksize == 3 and stride == 1 and pad == 1 and ups == 1 and cin % 16 == 0
+            and cout % 48 == 0)
+
+
+def transform_filters4(w_ohwi):
+    """[Cout, 3, 3, Cin] -> float32 [36, Cin // 16, Cout, 16], U[6 i + j] = (G g G^T)[i][j],
+    computed in float64 and rounded once."""
+    w = np.asarray(w_ohwi, np.float64)
+    cout, kh, kw, cin = w.shape
+    assert (kh, kw) == (3, 3) and cin % 16 == 0, w.shape
+    u = np.einsum('ia,oabc,jb->ijoc', G4, w, G4)                   # [6,6,Cout,Cin]
+    u = u.reshape(36, cout, cin // 16, 16).transpose(0, 2, 1, 3)   # [36, Cin/16, Cout, 16]
+    return np.ascontiguousarray(u, dtype=np.float32)
+
+
+def conv_reference4(x_nhwc, u, bias=None):
+    """NumPy restatement of the F(4x4,3x3) path for tests: x [B,H,W,Cin] -> [B,H,W,Cout]; u from
+    ``transform_filters4``.  float32 transforms, float64 accumulation of the products."""
+    f32 = np.float32
+    x = np.asarray(x_nhwc, f32)
+    B, H, W, C = x.shape
+    cout = u.shape[2]
+    TH, TW = (H + 3) // 4, (W + 3) // 4
+    xp = np.zeros((B, 4 * TH + 2, 4 * TW + 2, C), f32)
+    xp[:, 1:H + 1, 1:W + 1] = x
+    d = np.stack([np.stack([xp[:, i:i + 4 * TH:4, k:k + 4 * TW:4] for k in range(6)], axis=3)
+                  for i in range(6)], axis=3)                       # [b,ty,tx,i,k,c]
+    bt = BT4.astype(f32)
+    t = np.einsum('jk,byxikc->byxijc', bt, d).astype(f32)          # d B   (along x)
+    v = np.einsum('li,byxijc->byxljc', bt, t).astype(f32)          # B^T (d B)
+    uu = u.transpose(0, 2, 1, 3).reshape(6, 6, cout, C)
+    m = np.einsum('byxijc,ijoc->byxijo', v.astype(np.float64), uu.astype(np.float64)).astype(f32)
+    at = AT4.astype(f32)
+    s = np.einsum('qj,byxijo->byxiqo', at, m).astype(f32)          # M A   (along x)
+    yt = np.einsum('pi,byxiqo->byxpqo', at, s).astype(f32)         # A^T (M A)
+    y = yt.transpose(0, 1, 3, 2, 4, 5).reshape(B, 4 * TH, 4 * TW, cout)[:, :H, :W]
+    if bias is not None:
+        y = y + np.asarray(bias, f32)
+    return y.astype(f32)

@@ -57,7 +57,12 @@ def _conv_call(lib, x, w, b, res=None, relu=False, stride=1, pad=0, ups=1, tile=
     d.out_ld = out_ld or O; d.out_coff = out_coff
     d.res_ld = (out_ld or O) if res is not None else 0; d.res_coff = out_coff if res is not None else 0
     d.relu = int(relu); d.ups = ups; d.tile = tile
-    if wino:                                           # Winograd-transformed filters as well
+    if wino == 4:                                      # F(4x4,3x3) filters (conv_wino4.hip)
+        from shapy_amd.utils import winograd
+        wu = torch.from_numpy(winograd.transform_filters4(w.cpu().numpy())).to(x.device)
+        d.wgt_wino = wu.data_ptr()
+        d.tile = tile | _lib.TILE_WINO4
+    elif wino:                                         # Winograd-transformed filters as well
         from shapy_amd.utils import winograd
         wu = torch.from_numpy(winograd.transform_filters(w.cpu().numpy())).to(x.device)
         d.wgt_wino = wu.data_ptr()
@@ -184,6 +189,81 @@ def test_conv_winograd_concat_offset(lib):
     ref = _conv_ref(x, w, b, before[..., 16:64], True, 1, 1)
     assert (big[..., 16:64].cpu().double() - ref).abs().max().item() < 2e-5
     assert torch.equal(big[..., :16], before[..., :16]) and torch.equal(big[..., 64:], before[..., 64:])
+
+
+WINO4_CASES = [
+    (1, 8, 8, 16, 48, False, False),       # 4 tiles: one partly filled workgroup, one K chunk
+    (2, 12, 20, 48, 48, True, True),       # 30 tiles: two workgroups, the unrolled 3-chunk kernel
+    (1, 7, 9, 32, 96, True, False),        # partial edge tiles (masked rows / columns), 2 N blocks
+    (3, 14, 14, 48, 48, True, True),
+    (2, 5, 6, 16, 48, False, True),
+    (2, 28, 28, 96, 96, True, True),       # the 28x28-branch layer class (unrolled 6 chunks)
+    (2, 56, 56, 48, 48, True, True),       # the 56x56-branch layer class
+    (1, 56, 56, 256, 48, False, True),     # transition1: 16 chunks through the generic loop
+    (1, 14, 14, 192, 192, True, True),
+    (1, 7, 7, 384, 384, True, True),       # N-slab order (transformed filters > 2 MB)
+    (5, 4, 4, 16, 48, False, False),       # one tile per image, 5 of 16 tiles live
+    (1, 3, 3, 16, 48, True, False),        # smaller than one tile
+]
+
+
+@pytest.mark.parametrize('case', WINO4_CASES, ids=[str(c) for c in WINO4_CASES])
+def test_conv_winograd4_kernel_vs_float64(lib, case):
+    """csrc/conv_wino4.hip (F(4x4,3x3), staging wave + three multiplying waves) through
+    shapy_conv2d (ShapyConv.wgt_wino + SHAPY_TILE_WINO4) against float64, next to the direct
+    kernel on the same operands."""
+    B, H, W, Cin, Cout, use_res, relu = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / np.sqrt(9 * Cin)).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(B, H, W, Cout, generator=g).cuda() if use_res else None
+    out = _conv_call(lib, x, w, b, res, relu, 1, 1, wino=4)
+    direct = _conv_call(lib, x, w, b, res, relu, 1, 1, tile=0x2000)
+    ref = _conv_ref(x, w, b, res, relu, 1, 1)
+    e = (out.cpu().double() - ref).abs()
+    ed = (direct.cpu().double() - ref).abs().max().item()
+    if not e.max().item() < 3e-5:           # localise: which pixels / channels are off
+        bad = (e > 3e-5)
+        print('bad fraction', bad.float().mean().item(), 'max', e.max().item(), 'direct err', ed)
+        print('bad per row y:', bad.any(dim=3).any(dim=2).any(dim=0).int().tolist())
+        print('bad per col x:', bad.any(dim=3).any(dim=1).any(dim=0).int().tolist())
+        print('bad per channel:', bad.any(dim=2).any(dim=1).any(dim=0).int().tolist())
+        print('bad per image:', bad.any(dim=3).any(dim=2).any(dim=1).int().tolist())
+    assert ed < 2e-5, ed
+    # F(4x4) transforms multiply by up to 8 / 5: a few float32 ulp more than F(2x2)
+    assert e.max().item() < 3e-5, e.max().item()
+    assert not torch.equal(out, direct) or Cin * H * W < 300   # really a different algorithm
+
+
+def test_conv_winograd4_concat_offset_and_refusals(lib):
+    """F(4x4) epilogue with out_ld > Cout / channel offset and an in-place residual; layers the
+    kernel does not take are refused (there is no fallback for the F(4x4) filter layout)."""
+    from shapy_amd import _lib
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 10, 10, 32, generator=g).cuda()
+    w = (torch.randn(48, 3, 3, 32, generator=g) / 17).cuda()
+    b = torch.randn(48, generator=g).cuda()
+    big = torch.randn(2, 10, 10, 112, generator=g).cuda()
+    before = big.clone()
+    _conv_call(lib, x, w, b, res=big, relu=True, stride=1, pad=1, out=big, out_ld=112,
+               out_coff=16, wino=4)
+    ref = _conv_ref(x, w, b, before[..., 16:64], True, 1, 1)
+    assert (big[..., 16:64].cpu().double() - ref).abs().max().item() < 3e-5
+    assert torch.equal(big[..., :16], before[..., :16]) and torch.equal(big[..., 64:], before[..., 64:])
+    # Cout = 64 has no 48-channel N tiling; stride 2 is not a Winograd layer
+    for cout, stride in ((64, 1), (48, 2)):
+        w2 = torch.randn(cout, 3, 3, 32, generator=g).cuda()
+        d = _lib.ShapyConv()
+        out = torch.empty(2, 10, 10, cout, device='cuda')
+        d.in_ = x.data_ptr(); d.wgt = w2.data_ptr(); d.out = out.data_ptr()
+        d.wgt_wino = w2.data_ptr()
+        d.B, d.Hi, d.Wi, d.Cin, d.in_ld = 2, 10, 10, 32, 32
+        d.Ho = d.Wo = (10 + 2 - 3) // stride + 1
+        d.Cout, d.ksize, d.stride, d.pad = cout, 3, stride, 1
+        d.out_ld = cout; d.ups = 1; d.tile = _lib.TILE_WINO4; d.dtype = _lib.DTYPE_F32
+        rc = lib.shapy_conv2d(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc != 0, (cout, stride)
 
 
 X6_CASES = [c for c in CONV_CASES if c[10] in (0, 5, 8, 2, 6, 3, 7)] + [
@@ -339,6 +419,37 @@ def test_hrnet_winograd_features_vs_reference_golden(network, golden_dir, tag, b
     err = np.abs(feat.cpu().numpy() - g[tag]).max()
     print(tag, algo, 'winograd layers', n_wino, 'max abs err', err)
     assert n_wino > (100 if algo == 'winograd' else 0)
+    assert err < 1e-4, err
+
+
+@pytest.mark.parametrize('tag,b,s', [('b2_64', 2, 64), ('b3_96', 3, 96), ('b1_224', 1, 224)])
+def test_hrnet_winograd4_features_vs_reference_golden(network, golden_dir, tag, b, s):
+    """conv_algo = 'winograd4': F(4x4,3x3) (csrc/conv_wino4.hip) on the large maps, F(2x2,3x3) on
+    the rest, against the reference's CPU features at 1e-4.  The small inputs lower the map-size
+    threshold so that they, too, run F(4x4) layers (incl. partly filled tiles: 24 / 4, 12 / 4)."""
+    from shapy_amd import _lib
+    from shapy_amd.utils import synthetic as syn
+    g = np.load(osp.join(golden_dir, 'hrnet_golden.npz'))
+    x = torch.from_numpy(syn.synthetic_images(b, s, 0)).cuda()
+    bb = network.backbone
+    bb.multi_stream = True
+    bb.conv_algo = 'winograd4'
+    keep = bb.wino4_min_hw
+    if s < 224:
+        bb.wino4_min_hw = 6
+    try:
+        with torch.no_grad():
+            feat = bb(x)['concat']
+        torch.cuda.synchronize()
+        eng = [e for k, e in bb._engine.items() if k[4] == 'winograd4' and k[0] == s][-1]
+        n4 = sum(1 for o in eng['plan'].ops if o['tile'] & _lib.TILE_WINO4)
+        n2 = sum(1 for o in eng['plan'].ops if o.get('wino_off', -1) >= 0) - n4
+    finally:
+        bb.conv_algo = 'direct'
+        bb.wino4_min_hw = keep
+    err = np.abs(feat.cpu().numpy() - g[tag]).max()
+    print(tag, 'F(4x4) layers', n4, 'F(2x2) layers', n2, 'max abs err', err)
+    assert n4 >= 100 and n2 > 0
     assert err < 1e-4, err
 
 
@@ -620,7 +731,7 @@ def _oracle_bs64():
     return _BS64['x'], _BS64['ref']
 
 
-@pytest.mark.parametrize('cdt', ['f32', 'f32x6', 'f32+winograd'])
+@pytest.mark.parametrize('cdt', ['f32', 'f32x6', 'f32+winograd', 'f32+winograd4'])
 def test_full_forward_bs64_vs_oracle(network, cdt):
     """BASELINE configs[1] at ITS OWN size: B = 64 @224, four streams on the liveness-packed
     arena, the tile instantiations the dispatcher picks at this M.  features / betas /
@@ -629,7 +740,8 @@ def test_full_forward_bs64_vs_oracle(network, cdt):
     x = torch.from_numpy(x_np).cuda()
     network.backbone.multi_stream = True
     network.backbone.compute_dtype = cdt.split('+')[0]
-    network.backbone.conv_algo = 'auto' if cdt.endswith('winograd') else 'direct'
+    network.backbone.conv_algo = {'winograd': 'auto', 'winograd4': 'winograd4'}.get(
+        cdt.split('+')[-1], 'direct')
     try:
         with torch.no_grad():
             out = network(x, None)

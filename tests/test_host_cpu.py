@@ -234,6 +234,44 @@ def test_winograd_plan_covers_the_3x3_stride1_layers(hrnet):
     np.testing.assert_allclose(u[:, 1, 5, 3].reshape(4, 4), winograd.G @ g @ winograd.G.T, rtol=1e-6)
 
 
+def test_winograd4_plan_filters_and_kernel_indexing(hrnet):
+    """conv_algo = 'winograd4': F(4x4,3x3) on the large maps only, flagged by SHAPY_TILE_WINO4;
+    the filter layout; the NumPy restatement against a float64 direct convolution; and the
+    thread-by-thread emulation of csrc/conv_wino4.hip's indexing (tools/wino4_emulate.py)."""
+    import importlib.util
+    from shapy_amd import _lib
+    from shapy_amd.utils import winograd
+    hrnet.conv_algo = 'winograd4'
+    try:
+        P = hrnet._build_plan(224, 224)
+    finally:
+        hrnet.conv_algo = 'winograd'
+    w4 = [o for o in P.ops if o['type'] == 0 and o['tile'] & _lib.TILE_WINO4]
+    w2 = [o for o in P.ops if o.get('wino_off', -1) >= 0 and not o['tile'] & _lib.TILE_WINO4]
+    assert len(w4) == 129 and len(w2) == 89
+    assert all(min(o['Hi'], o['Wi']) >= hrnet.wino4_min_hw and o['Cout'] % 48 == 0 and
+               o['wino_off'] >= 0 for o in w4)
+    assert not any(o['tile'] & _lib.TILE_WINO4 for o in hrnet._build_plan(224, 224).ops)
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((48, 3, 3, 32)) / 17).astype(np.float32)
+    u = winograd.transform_filters4(w)
+    assert u.shape == (36, 2, 48, 16)
+    g = w[5, :, :, 19].astype(np.float64)
+    np.testing.assert_allclose(u[:, 1, 5, 3].reshape(6, 6), winograd.G4 @ g @ winograd.G4.T,
+                               rtol=1e-6, atol=1e-7)
+    spec = importlib.util.spec_from_file_location('wino4_emulate',
+                                                  osp.join(ROOT, 'tools', 'wino4_emulate.py'))
+    emu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(emu)
+    x = rng.standard_normal((2, 9, 7, 32)).astype(np.float32)
+    b = rng.standard_normal(48).astype(np.float32)
+    y = winograd.conv_reference4(x, u, b)
+    assert np.abs(y - emu.direct_conv(x, w, b)).max() < 2e-5
+    emu.check(2, 12, 20, 48, 48, True, True)             # two workgroups, 3 chunks, residual
+    emu.check(1, 7, 9, 32, 96, True, False)              # partial edge tiles, two N tiles
+    emu.check(1, 14, 14, 16, 48, False, False, coff=16)  # channel-offset epilogue
+
+
 def test_regressor_stage_collapse_matches_the_iteration():
     """The fully collapsed regressor (W_all, b_all of shapy_regressor_collapsed_f32) against the
     layer-by-layer float32 iteration of the oracle (networks.py:536-592)."""

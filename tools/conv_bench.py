@@ -1,6 +1,6 @@
 """Per-shape microbenchmark of the MFMA conv kernel over the conv classes of HRNet-W48.
 
-    python tools/conv_bench.py [--batch 64] [--size 224] [--tiles auto,wino,256x48,...] [--out file]
+    python tools/conv_bench.py [--batch 64] [--size 224] [--tiles auto,wino,wino4,256x48,...] [--out file]
 
 For every distinct (Hi, Cin, Cout, ksize, stride, ups, residual) class of the backbone's op
 list it times shapy_conv2d alone on the GPU (HIP events, single stream) and prints
@@ -31,6 +31,8 @@ def main():
     ap.add_argument('--out', default='')
     ap.add_argument('--filter', default='', help='Hi,Cin,Cout,ksize: run only this class')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f32x6'])
+    ap.add_argument('--wino4-min-hw', type=int, default=7,
+                    help='tile "wino4": only maps of at least this many pixels a side')
     args = ap.parse_args()
     lib = _lib.load()
     net = HighResolutionNet(default_config().network.smplx.backbone.hrnet)
@@ -64,10 +66,18 @@ def main():
         out = torch.empty(B, Ho * ups, Wo * ups, Cout, device='cuda', dtype=tdt)
         res = torch.randn_like(out) if has_res else None
         flop = 2.0 * B * Ho * Wo * Cout * Cin * ks * ks
-        wu = None
+        wu = wu4 = None
         for tile in args.tiles.split(','):
             d = _lib.ShapyConv()
-            if tile in ('wino', 'wino1', 'wino2', 'winochunk'):     # Winograd F(2x2,3x3) where it applies
+            if tile == 'wino4':                                     # Winograd F(4x4,3x3) (conv_wino4.hip)
+                from shapy_amd.utils import winograd
+                if args.dtype != 'f32' or not winograd.eligible4(ks, st, pad, Cin, Cout, ups) \
+                        or min(Hi, Wi) < args.wino4_min_hw:
+                    continue
+                if wu4 is None:
+                    wu4 = torch.from_numpy(winograd.transform_filters4(w.cpu().numpy())).cuda()
+                d.wgt_wino = wu4.data_ptr()
+            elif tile in ('wino', 'wino1', 'wino2', 'winochunk'):   # Winograd F(2x2,3x3) where it applies
                 from shapy_amd.utils import winograd
                 if args.dtype != 'f32' or not winograd.eligible(ks, st, pad, Cin, Cout, ups):
                     continue
@@ -81,7 +91,8 @@ def main():
             d.Ho, d.Wo, d.Cout = Ho, Wo, Cout
             d.ksize, d.stride, d.pad = ks, st, pad
             d.out_ld = Cout; d.out_coff = 0; d.res_ld = Cout if has_res else 0; d.res_coff = 0
-            d.relu = int(relu); d.ups = ups; d.tile = {'wino': 0, 'wino1': 0x4000, 'wino2': 0x8000, 'winochunk': 0x20000}[tile] if tile.startswith('wino') else _lib.TILES[tile]
+            d.relu = int(relu); d.ups = ups; d.tile = {'wino': 0, 'wino1': 0x4000, 'wino2': 0x8000, 'winochunk': 0x20000,
+                                                     'wino4': _lib.TILE_WINO4}[tile] if tile.startswith('wino') else _lib.TILES[tile]
             d.dtype = {'f32': _lib.DTYPE_F32, 'bf16': _lib.DTYPE_BF16, 'f32x6': _lib.DTYPE_F32X6}[args.dtype]
             rc = 0
             for _ in range(2):
