@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
     const __amdgpu_buffer_rsrc_t rs_in =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
     const int tile_s = lane >> 2, c4 = lane & 3;
-    int row_off[6], col_off[6];
+    unsigned row_off[6], col_off[6];            // (unsigned: two invalid parts sum to 2 GiB)
     {
       const int pix_stride = p.in_ld * 4;
       const int tile = m_blk + tile_s;
@@ -137,12 +137,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
     auto gload_col = [&](int j, int c0) {              // column j of the patch, channels c0 ..
       // (the asm keeps the chunk offset inside the sum: hipcc otherwise hoists the 36
       // loop-invariant row + column sums out of the K loop and spills them to scratch)
-      int co = col_off[j] + c0 * 4;
+      unsigned co = col_off[j] + c0 * 4;
       asm volatile("" : "+v"(co));
 #pragma unroll
       for (int i = 0; i < 6; ++i)
         raw[i][j] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, row_off[i] + co, 0, 0));
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(row_off[i] + co), 0, 0));
     };
 #pragma unroll
     for (int j = 0; j < 6; ++j) gload_col(j, 0);

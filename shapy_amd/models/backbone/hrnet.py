@@ -20,6 +20,7 @@ nearest-upsample + add of the fuse layers and the channel concat fused into its 
 The independent branches of a HighResolutionModule are issued on separate HIP streams.
 """
 import ctypes
+import os
 import os.path as osp
 
 import numpy as np
@@ -31,6 +32,9 @@ from ...utils.versioning import VersionedWeights
 from ...utils import winograd
 
 BN_MOMENTUM = 0.1
+#: product defaults of HighResolutionNet.conv_algo / .wino4_min_hw (see there)
+DEFAULT_CONV_ALGO = 'winograd'
+DEFAULT_WINO4_MIN_HW = 28
 
 
 # ------------------------------------------------------------------------------------------
@@ -352,9 +356,11 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: 'winograd4' = F(4x4,3x3) (csrc/conv_wino4.hip: 36 instead of 64 multiplies per 4x4
         #: outputs, 48-channel N tiles) on maps of at least wino4_min_hw pixels a side --
         #: smaller maps have too few 4x4 tiles to fill the chip --, F(2x2,3x3) on the rest
-        self.conv_algo = 'winograd'
+        #: (SHAPY_CONV_ALGO / SHAPY_WINO4_MIN_HW override the defaults: A/B runs of whole test
+        #: suites and benches under another default without editing code)
+        self.conv_algo = os.environ.get('SHAPY_CONV_ALGO', DEFAULT_CONV_ALGO)
         self.wino_min_hw = 14
-        self.wino4_min_hw = 28
+        self.wino4_min_hw = int(os.environ.get('SHAPY_WINO4_MIN_HW', DEFAULT_WINO4_MIN_HW))
         self._engine_ver = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
 

@@ -6,6 +6,7 @@ golden vectors produced by the real reference.  Tolerances (float32 path):
   * mesh-mesh intersection op: bit-exact faces and barycentrics vs the C oracle
 """
 import ctypes
+import os
 import os.path as osp
 
 import numpy as np
@@ -393,7 +394,9 @@ def network():
     net = build_model(cfg)['network']
     syn.fill_module_synthetic(net, 0)
     net = net.to('cuda').eval()
-    assert net.backbone.conv_algo == 'winograd'        # the product default (smoke / bench use it)
+    from shapy_amd.models.backbone import hrnet as hrnet_mod
+    # the product default (smoke / bench use it; SHAPY_CONV_ALGO overrides it for A/B runs)
+    assert net.backbone.conv_algo == os.environ.get('SHAPY_CONV_ALGO', hrnet_mod.DEFAULT_CONV_ALGO)
     net.backbone.conv_algo = 'direct'                  # baseline of this module: the exact-f32
     return net                                         # direct path; Winograd tests opt in
 
