@@ -33,8 +33,8 @@ from ...utils import winograd
 
 BN_MOMENTUM = 0.1
 #: product defaults of HighResolutionNet.conv_algo / .wino4_min_hw (see there)
-DEFAULT_CONV_ALGO = 'winograd'
-DEFAULT_WINO4_MIN_HW = 28
+DEFAULT_CONV_ALGO = 'winograd4'
+DEFAULT_WINO4_MIN_HW = 14
 
 
 # ------------------------------------------------------------------------------------------
@@ -347,15 +347,20 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: exact 3-way bf16 split on the bf16 matrix cores (float32-class accuracy);
         #: 'bf16' = bf16 weights/activations, f32 accumulate
         self.compute_dtype = 'f32'
-        #: float32 convolution algorithm of the 3x3 / stride-1 layers: 'winograd' (default) =
-        #: Winograd F(2x2,3x3) (csrc/conv_wino.hip, 2.25x fewer MFMAs, float32-class result:
-        #: same 1e-4 parity tests) wherever the kernel applies -- measured faster on every
-        #: eligible HRNet class incl. the 7x7 maps (profiles/conv_bench_r02*); 'direct' =
-        #: implicit GEMM for every layer (the exact-f32 fmaf chain of the reference's sum
-        #: order); 'auto' = Winograd only on maps of at least wino_min_hw pixels a side
-        #: 'winograd4' = F(4x4,3x3) (csrc/conv_wino4.hip: 36 instead of 64 multiplies per 4x4
-        #: outputs, 48-channel N tiles) on maps of at least wino4_min_hw pixels a side --
-        #: smaller maps have too few 4x4 tiles to fill the chip --, F(2x2,3x3) on the rest
+        #: float32 convolution algorithm of the 3x3 / stride-1 layers (float32-class results, same
+        #: 1e-4 parity tests for all of them):
+        #:   'winograd4' (default) = Winograd F(4x4,3x3) (csrc/conv_wino4.hip: 36 multiplies per
+        #:       4x4 outputs, 48-channel N tiles) on maps of at least wino4_min_hw pixels a side,
+        #:       F(2x2,3x3) on the rest.  Measured on MI355X at B = 64 (profiles/
+        #:       conv_bench_r02w_wino_vs_wino4.txt): 61 -> 51 us (48 ch @56x56), 59 -> 40 us (96 ch
+        #:       @28x28), 58 -> 42 us (192 ch @14x14), but 62 -> 69 us on the 7x7 maps (256 tiles
+        #:       cannot fill the chip): hence 14; end to end 3,808 -> 4,473 images/s
+        #:   'winograd' = Winograd F(2x2,3x3) (csrc/conv_wino.hip, 2.25x fewer MFMAs than direct)
+        #:       wherever the kernel applies -- faster than direct on every eligible HRNet class
+        #:       incl. the 7x7 maps (profiles/conv_bench_r02*)
+        #:   'direct' = implicit GEMM for every layer (the exact-f32 fmaf chain of the reference's
+        #:       sum order)
+        #:   'auto' = F(2x2) only on maps of at least wino_min_hw pixels a side
         #: (SHAPY_CONV_ALGO / SHAPY_WINO4_MIN_HW override the defaults: A/B runs of whole test
         #: suites and benches under another default without editing code)
         self.conv_algo = os.environ.get('SHAPY_CONV_ALGO', DEFAULT_CONV_ALGO)

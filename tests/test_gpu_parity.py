@@ -224,16 +224,24 @@ def test_conv_winograd4_kernel_vs_float64(lib, case):
     ref = _conv_ref(x, w, b, res, relu, 1, 1)
     e = (out.cpu().double() - ref).abs()
     ed = (direct.cpu().double() - ref).abs().max().item()
-    if not e.max().item() < 3e-5:           # localise: which pixels / channels are off
-        bad = (e > 3e-5)
+    if not e.max().item() < 2e-6 * np.sqrt(9 * Cin):   # localise: which pixels / channels are off
+        bad = (e > 2e-6 * np.sqrt(9 * Cin))
         print('bad fraction', bad.float().mean().item(), 'max', e.max().item(), 'direct err', ed)
         print('bad per row y:', bad.any(dim=3).any(dim=2).any(dim=0).int().tolist())
         print('bad per col x:', bad.any(dim=3).any(dim=1).any(dim=0).int().tolist())
         print('bad per channel:', bad.any(dim=2).any(dim=1).any(dim=0).int().tolist())
         print('bad per image:', bad.any(dim=3).any(dim=2).any(dim=1).int().tolist())
     assert ed < 2e-5, ed
-    # F(4x4) transforms multiply by up to 8 / 5: a few float32 ulp more than F(2x2)
-    assert e.max().item() < 3e-5, e.max().item()
+    # F(4x4) transforms multiply by up to 8 (data) and 1/24 .. 1/4 (filters): on these unit-variance
+    # random operands its float32 rounding is ~6x the direct sum's and grows with sqrt(K) -- first
+    # GPU run: 5.1e-5 at K = 2,304, 4.7e-5 at K = 3,456, <= 2.5e-5 at K <= 864, direct 5..9e-6.
+    # (On the network's real activations the F(4x4) features are as close to the CPU reference
+    # as the direct ones: 4.3e-6 at bs 64, test_full_forward_bs64_vs_oracle.)  An indexing bug
+    # would show up as O(1) errors.
+    tol = 2e-6 * np.sqrt(9 * Cin)
+    if not e.max().item() < tol:
+        print('tolerance', tol)
+    assert e.max().item() < tol, (e.max().item(), tol)
     assert not torch.equal(out, direct) or Cin * H * W < 300   # really a different algorithm
 
 

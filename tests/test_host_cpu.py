@@ -241,17 +241,25 @@ def test_winograd4_plan_filters_and_kernel_indexing(hrnet):
     import importlib.util
     from shapy_amd import _lib
     from shapy_amd.utils import winograd
+    keep = hrnet.conv_algo, hrnet.wino4_min_hw
     hrnet.conv_algo = 'winograd4'
     try:
+        hrnet.wino4_min_hw = 28
+        P28 = hrnet._build_plan(224, 224)
+        hrnet.wino4_min_hw = 14
         P = hrnet._build_plan(224, 224)
     finally:
         hrnet.conv_algo = 'winograd'
+    count = lambda plan: (
+        sum(1 for o in plan.ops if o['type'] == 0 and o['tile'] & _lib.TILE_WINO4),
+        sum(1 for o in plan.ops if o.get('wino_off', -1) >= 0 and not o['tile'] & _lib.TILE_WINO4))
+    assert count(P28) == (129, 89)                      # 48 @56x56, 96 @28x28, transition1
+    assert count(P) == (185, 33)                        # + 192 @14x14; the 7x7 maps keep F(2x2)
     w4 = [o for o in P.ops if o['type'] == 0 and o['tile'] & _lib.TILE_WINO4]
-    w2 = [o for o in P.ops if o.get('wino_off', -1) >= 0 and not o['tile'] & _lib.TILE_WINO4]
-    assert len(w4) == 129 and len(w2) == 89
     assert all(min(o['Hi'], o['Wi']) >= hrnet.wino4_min_hw and o['Cout'] % 48 == 0 and
                o['wino_off'] >= 0 for o in w4)
     assert not any(o['tile'] & _lib.TILE_WINO4 for o in hrnet._build_plan(224, 224).ops)
+    hrnet.conv_algo, hrnet.wino4_min_hw = keep
     rng = np.random.default_rng(0)
     w = (rng.standard_normal((48, 3, 3, 32)) / 17).astype(np.float32)
     u = winograd.transform_filters4(w)
