@@ -64,6 +64,26 @@ def conv_flop_per_image(net, size):
     return 2 * macs
 
 
+def executed_mfma_flop_per_image(net, size):
+    """FLOPs the matrix cores actually execute per image with the backbone's conv_algo: direct
+    layers as counted above, Winograd F(2x2,3x3) layers 16 products per 2x2 tile and channel pair,
+    F(4x4,3x3) layers 36 per 4x4 tile (whole tiles: partly filled edge tiles count in full)."""
+    from shapy_amd import _lib
+    plan = net.backbone._build_plan(size, size)
+    macs = 0
+    for o in plan.ops:
+        if o['type'] == 2:
+            continue
+        cc = o['Cout'] * o['Cin']
+        if o.get('wino_off', -1) >= 0 and o['tile'] & _lib.TILE_WINO4:
+            macs += 36 * -(-o['Ho'] // 4) * -(-o['Wo'] // 4) * cc
+        elif o.get('wino_off', -1) >= 0:
+            macs += 16 * -(-o['Ho'] // 2) * -(-o['Wo'] // 2) * cc
+        else:
+            macs += o['Ho'] * o['Wo'] * cc * o['ksize'] ** 2
+    return 2 * macs
+
+
 def pmc_traffic(batch, size, dtype='f32', algo='direct'):
     """HBM bytes per backbone forward from the committed rocprofv3 --pmc passes
     (profiles/*_pmc_hbm_traffic*.json; FETCH_SIZE and WRITE_SIZE need separate passes and cannot
@@ -440,6 +460,15 @@ def run_regressor(args, rank, world, local_rank):
                      'flop_per_launch_group': flop_img * B,
                      'ms_per_launch_group': backbone_ms},
     }
+    if args.dtype == 'f32':
+        # `achieved` counts the direct-convolution FLOPs the layers DEFINE (the contract's
+        # algorithmic work); the Winograd layers execute 2.25x / 4x fewer multiplies, so with them
+        # `frac` can exceed 1.  What the matrix cores themselves execute, for comparison:
+        ex = executed_mfma_flop_per_image(net, args.size) * B / (backbone_ms * 1e-3) / 1e12
+        res['roofline']['executed_mfma'] = {
+            'tflops': ex, 'frac_of_peak': ex / peak,
+            'note': 'FLOPs issued to the f32 matrix cores (Winograd layers: 16 products per 2x2 '
+                    'tile, 36 per 4x4 tile and channel pair) / backbone time'}
     if world > 1:
         res['rccl_ranks'] = world
         res['per_rank'] = {'images_per_sec': per_rank,
