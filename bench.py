@@ -344,6 +344,8 @@ def run_regressor(args, rank, world, local_rank):
         net.backbone.conv_algo = args.algo
     if args.wino4_min_hw:
         net.backbone.wino4_min_hw = args.wino4_min_hw
+    if args.tile_flags:
+        net.backbone.tile_flags = int(args.tile_flags, 0)
     B = args.batch
     # distinct synthetic images per rank (global batch = world * B), resident in HBM
     x_np = syn.synthetic_images(B, args.size, 100 + rank)
@@ -504,6 +506,9 @@ def main():
                          '(6 bf16 MFMAs per product); bf16 = configs[2] storage type')
     ap.add_argument('--algo', default=None, choices=['direct', 'auto', 'winograd', 'winograd4'],
                     help='f32 conv algorithm override (default: the backbone\'s own default)')
+    ap.add_argument('--tile-flags', default='',
+                    help='A/B knob bits OR-ed into every conv\'s tile id (shapy_amd/_lib.py), e.g. '
+                         '0x200000 = F(4x4) kernel with the 12-chunk loop unrolled')
     ap.add_argument('--wino4-min-hw', type=int, default=0,
                     help='--algo winograd4: smallest map side that takes F(4x4,3x3) (default: the '
                          'backbone\'s own, 28)')

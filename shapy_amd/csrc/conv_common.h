@@ -47,6 +47,7 @@ struct ConvK {
   int flat;                     // bf16, Cin % 32 != 0: flat-K kernel
   int pd3;                      // implicit GEMM: three chunks of global loads in flight
   int dbg;                      // -DSHAPY_WINO_TIMING builds only: ablation mask (wrong results)
+  int w4_unroll12;              // tuning: F(4x4) kernel with the 12-chunk loop unrolled (Cin = 192)
 };
 
 // Winograd F(2x2,3x3) path of the float32 3x3 / stride-1 layers (conv_wino.hip)
@@ -54,6 +55,7 @@ bool conv_wino_eligible(const ConvK &k);
 int conv2d_wino(ConvK k, int tm, hipStream_t s);
 // Winograd F(4x4,3x3) path (conv_wino4.hip): k.wgt2 holds [36][Cin/16][Cout][16] filters
 int conv2d_wino4(ConvK k, hipStream_t s);
+bool conv_wino4_fits(const ConvK &k);
 
 // float32 storage, bf16x6 split arithmetic on the bf16 matrix cores (conv_x6.hip)
 int conv2d_x6(const ConvK &k, int tile, hipStream_t s);

@@ -354,6 +354,7 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   k.no_nslab = (d.tile & 0x10000) ? 1 : 0;
   k.no_allk = (d.tile & 0x20000) ? 1 : 0;
   k.dbg = 0;
+  k.w4_unroll12 = 0;
   k.flat = flat ? 1 : 0;
   // three chunks of global loads in flight: bf16 always (its chunks are 50-100 ns of MFMAs);
   // float32 on request (tile flag 0x40000, A/B benches)
@@ -363,7 +364,11 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   // kernel for that layout, so an ineligible layer is an error, not a fallback
   if (d.tile & 0x100000) {
     if (d.dtype != SHAPY_DTYPE_F32 || !conv_wino_eligible(k) || k.Cout % 48) return SHAPY_EINVAL;
-    return conv2d_wino4(k, s);
+    k.w4_unroll12 = (d.tile & 0x200000) ? 1 : 0;
+    if (conv_wino4_fits(k)) return conv2d_wino4(k, s);
+    // tensors beyond the kernel's 1 GiB offset scheme (B > 334 at 224x224): the direct kernel on
+    // the untransformed weights, which every layer carries -- slower, same convolution
+    k.wgt2 = nullptr;
   }
   if (d.dtype == SHAPY_DTYPE_F32 && !(d.tile & 0x2000) && conv_wino_eligible(k))
     return conv2d_wino(k, (d.tile & 0x4000) ? 1 : (d.tile & 0x8000) ? 2 : 0, s);

@@ -314,18 +314,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
   }
 }
 
+// The kernel marks invalid accesses with the byte offset 0x40000000: every tensor it touches has
+// to stay below 1 GiB (B <= 334 for HRNet's 256-channel 56x56 map).
+bool conv_wino4_fits(const ConvK &k) {
+  const unsigned long long lim = 0x40000000ull;
+  return k.Cout % 48 == 0 && k.in_bytes <= lim && 4ull * k.M * k.out_ld <= lim &&
+         (!k.res || 4ull * k.M * k.res_ld <= lim) && 144ull * k.Cin * k.Cout < 0x7fffffffull;
+}
+
 // tile flag 0x100000 of ShapyConv.tile: wgt_wino holds F(4x4,3x3) filters [36][Cin/16][Cout][16]
 int conv2d_wino4(ConvK k, hipStream_t s) {
+  if (!conv_wino4_fits(k)) return SHAPY_EINVAL;
   const int B = k.M / (k.Ho * k.Wo);
   k.wino_tiles = B * ((k.Hi + 3) / 4) * ((k.Wi + 3) / 4);
-  const unsigned long long wb = 144ull * k.Cin * k.Cout;       // 36 positions x f32
-  if (wb >= 0x7fffffffull) return SHAPY_EINVAL;
-  k.wgt2_bytes = (unsigned)wb;
-  // 0x40000000 doubles as the "out of range" byte offset of every buffer access in the kernel
-  const unsigned long long lim = 0x40000000ull;
-  if (k.Cout % 48 || k.in_bytes > lim || 4ull * k.M * k.out_ld > lim ||
-      (k.res && 4ull * k.M * k.res_ld > lim))
-    return SHAPY_EINVAL;
+  k.wgt2_bytes = (unsigned)(144ull * k.Cin * k.Cout);          // 36 positions x f32
   k.nbx = k.Cout / 48;
   k.nby = (k.wino_tiles + 15) / 16;
   // transformed filters larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
@@ -335,6 +337,10 @@ int conv2d_wino4(ConvK k, hipStream_t s) {
     hipLaunchKernelGGL(conv_wino4_kernel<3>, grid, blk, 0, s, k);
   else if (k.Cin == 96)
     hipLaunchKernelGGL(conv_wino4_kernel<6>, grid, blk, 0, s, k);
+  else if (k.Cin == 192 && k.w4_unroll12)
+    // A/B knob (tile flag 0x200000), not measured yet: the 192-channel class spends ~0.7 us per
+    // chunk in the generic loop's vmcnt(0) drain (42 us for 12 chunks of 2.2 us of MFMA issue)
+    hipLaunchKernelGGL(conv_wino4_kernel<12>, grid, blk, 0, s, k);
   else
     hipLaunchKernelGGL(conv_wino4_kernel<0>, grid, blk, 0, s, k);
   return (int)hipGetLastError();

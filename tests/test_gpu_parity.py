@@ -275,6 +275,25 @@ def test_conv_winograd4_concat_offset_and_refusals(lib):
         assert rc != 0, (cout, stride)
 
 
+def test_conv_winograd4_falls_back_to_direct_beyond_1gib(lib):
+    """The F(4x4) kernel addresses with 32-bit byte offsets and uses 0x40000000 as its "out of
+    range" mark: a tensor beyond 1 GiB (here: a channel slice of a 1.08 GB concat buffer) makes
+    shapy_conv2d run the direct kernel on the untransformed weights instead -- same result."""
+    g = torch.Generator().manual_seed(13)
+    B, H, W, C, O, LD = 21, 56, 56, 48, 48, 4096
+    assert 4 * B * H * W * LD > 0x40000000
+    x = torch.randn(B, H, W, C, generator=g).cuda()
+    w = (torch.randn(O, 3, 3, C, generator=g) / np.sqrt(9 * C)).cuda()
+    b = torch.randn(O, generator=g).cuda()
+    big = torch.zeros(B, H, W, LD, device='cuda')
+    _conv_call(lib, x, w, b, relu=True, stride=1, pad=1, out=big, out_ld=LD, out_coff=64, wino=4)
+    direct = _conv_call(lib, x, w, b, relu=True, stride=1, pad=1, tile=0x2000)
+    assert torch.equal(big[..., 64:64 + O], direct)          # the very same kernel ran
+    assert not big[..., :64].any() and not big[..., 64 + O:].any()
+    ref = _conv_ref(x[:2], w, b, None, True, 1, 1)
+    assert (direct[:2].cpu().double() - ref).abs().max().item() < 2e-5
+
+
 X6_CASES = [c for c in CONV_CASES if c[10] in (0, 5, 8, 2, 6, 3, 7)] + [
     (2, 12, 12, 48, 48, 3, 1, 1, True, True, 8),      # Cin = 48: K chunks straddle taps
     (2, 9, 11, 20, 70, 3, 1, 1, False, False, 0),     # Cin % 32 != 0, Cin < 32, N tail
