@@ -57,19 +57,28 @@ def baseline_metric():
         return 'images/sec whole-node (HRNet+SMPL-X fwd), 224×224 bs=64; betas L2 vs CPU'
 
 
-def conv_flop_per_image(net, size):
-    plan = net.backbone._build_plan(size, size)      # f32 plan: algorithmic (unpadded) MACs
+def _f32_plan(net, size):
+    """The backbone's float32 op list at this size: the compiled engine's own plan when the run
+    is float32, a freshly built one otherwise (the bf16 / f32x6 plans pad channels)."""
+    for key, eng in net.backbone._engine.items():
+        if key[0] == size and key[1] == size and key[3] == 'f32':
+            return eng['plan']
+    return net.backbone._build_plan(size, size)
+
+
+def conv_flop_per_image(net, size, plan=None):
+    plan = plan or _f32_plan(net, size)              # f32 plan: algorithmic (unpadded) MACs
     macs = sum(o['Ho'] * o['Wo'] * o['Cout'] * o['Cin'] * o['ksize'] ** 2
                for o in plan.ops if o['type'] != 2)
     return 2 * macs
 
 
-def executed_mfma_flop_per_image(net, size):
+def executed_mfma_flop_per_image(net, size, plan=None):
     """FLOPs the matrix cores actually execute per image with the backbone's conv_algo: direct
     layers as counted above, Winograd F(2x2,3x3) layers 16 products per 2x2 tile and channel pair,
     F(4x4,3x3) layers 36 per 4x4 tile (whole tiles: partly filled edge tiles count in full)."""
     from shapy_amd import _lib
-    plan = net.backbone._build_plan(size, size)
+    plan = plan or _f32_plan(net, size)
     macs = 0
     for o in plan.ops:
         if o['type'] == 2:
