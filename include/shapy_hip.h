@@ -99,6 +99,7 @@ typedef struct ShapyConv {
                          never Winograd, 0x4000 / 0x8000 Winograd tile groups, 0x20000 Winograd K
                          loop chunk by chunk, 0x40000 / 0x80000 three / one chunk(s) of loads in
                          flight.  Speed only: every setting computes the same convolution.
+                         (0x200000: F(4x4) kernel with its 12-chunk loop unrolled, Cin = 192.)
                          One bit describes DATA instead: SHAPY_TILE_WINO4 (0x100000) says that
                          wgt_wino holds F(4x4,3x3) filters (below).                             */
   int32_t dtype;      /* storage type of in / wgt / res / out: SHAPY_DTYPE_F32 (f32 MFMA, exact
@@ -113,9 +114,10 @@ typedef struct ShapyConv {
                          equal to the direct sum up to float32 rounding of the transforms.
                          With SHAPY_TILE_WINO4 set in `tile`: the F(4x4,3x3) transform instead,
                          U[p = 6i+j][Cin/16][Cout][16] with the 6x3 G of the points {0, +-1, +-2,
-                         inf} (winograd.transform_filters4); needs Cout % 48 == 0 and tensors of
-                         at most 1 GiB; runs on csrc/conv_wino4.hip (4x fewer MFMAs than the
-                         direct sum); SHAPY_EINVAL when the layer does not qualify.           */
+                         inf} (winograd.transform_filters4); needs Cout % 48 == 0; runs on
+                         csrc/conv_wino4.hip (4x fewer MFMAs than the direct sum).  Tensors
+                         beyond 1 GiB (the kernel's 32-bit offset scheme) run the direct kernel
+                         on `wgt` instead; SHAPY_EINVAL when the layer shape does not qualify.  */
 } ShapyConv;
 #define SHAPY_TILE_WINO4 0x100000
 
