@@ -280,6 +280,28 @@ def test_winograd4_plan_filters_and_kernel_indexing(hrnet):
     emu.check(1, 14, 14, 16, 48, False, False, coff=16)  # channel-offset epilogue
 
 
+def test_bench_flop_accounting_algorithmic_vs_executed(hrnet):
+    """bench.py: `roofline.achieved` counts the direct-convolution FLOPs of SURVEY.md 8(d) whatever
+    the algorithm; `executed_mfma` what the matrix cores run (F(2x2): 16 products per 2x2 tile,
+    F(4x4): 36 per 4x4 tile)."""
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    net = types.SimpleNamespace(backbone=hrnet)
+    keep = hrnet.conv_algo, hrnet.wino4_min_hw
+    try:
+        got = {}
+        for algo in ('direct', 'winograd', 'winograd4'):
+            hrnet.conv_algo, hrnet.wino4_min_hw = algo, 14
+            got[algo] = (bench.conv_flop_per_image(net, 224), bench.executed_mfma_flop_per_image(net, 224))
+    finally:
+        hrnet.conv_algo, hrnet.wino4_min_hw = keep
+    assert {a for a, _ in got.values()} == {bench.CONV_FLOP_PER_IMAGE_224}
+    assert got['direct'][1] == bench.CONV_FLOP_PER_IMAGE_224
+    assert 1.7 < got['winograd'][0] / got['winograd'][1] < 1.8          # 89 % of the MACs / 2.25
+    assert 2.15 < got['winograd4'][0] / got['winograd4'][1] < 2.25      # F(4x4) from 14 px
+
+
 def test_regressor_stage_collapse_matches_the_iteration():
     """The fully collapsed regressor (W_all, b_all of shapy_regressor_collapsed_f32) against the
     layer-by-layer float32 iteration of the oracle (networks.py:536-592)."""
