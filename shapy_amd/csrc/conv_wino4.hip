@@ -338,8 +338,9 @@ int conv2d_wino4(ConvK k, hipStream_t s) {
   else if (k.Cin == 96)
     hipLaunchKernelGGL(conv_wino4_kernel<6>, grid, blk, 0, s, k);
   else if (k.Cin == 192 && k.w4_unroll12)
-    // A/B knob (tile flag 0x200000), not measured yet: the 192-channel class spends ~0.7 us per
-    // chunk in the generic loop's vmcnt(0) drain (42 us for 12 chunks of 2.2 us of MFMA issue)
+    // A/B knob (tile flag 0x200000): bit-identical to the generic loop and no faster (40.9 vs
+    // 41.3 us at B = 64, profiles/r02y_wino4_unroll12_192.txt) -- the vmcnt(0) drain at the
+    // header of the generic loop is not what bounds the 192-channel class
     hipLaunchKernelGGL(conv_wino4_kernel<12>, grid, blk, 0, s, k);
   else
     hipLaunchKernelGGL(conv_wino4_kernel<0>, grid, blk, 0, s, k);

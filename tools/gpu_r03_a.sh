@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 R=$PWD
 echo "== PMC: HBM bytes + MFMA busy cycles of the F(4x4) default (roofline.traffic)"
 timeout 900 bash tools/pmc_hbm_traffic.sh gpurun_out/a_pmc_hbm_traffic_winograd4 f32 winograd4 | grep -A8 hbm_bytes
-echo "== F(4x4) kernel: 12-chunk loop unrolled for Cin = 192 (tile flag 0x200000)"
+echo "== F(4x4) kernel: 12-chunk loop unrolled for Cin = 192 (tile flag 0x200000; round 2 run Y: 40.9 vs 41.3 us, no gain)"
 timeout 200 python tools/conv_bench.py --tiles wino4,wino4u12 --filter 14,192,192,3 --iters 20 | grep wino4
 timeout 200 python bench.py --steps 15 --warmup 4 --no-cpu-baseline | cut -c90-200
 timeout 200 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --tile-flags 0x200000 | cut -c90-200
