@@ -365,7 +365,8 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   if (d.tile & 0x100000) {
     if (d.dtype != SHAPY_DTYPE_F32 || !conv_wino_eligible(k) || k.Cout % 48) return SHAPY_EINVAL;
     k.w4_unroll12 = (d.tile & 0x200000) ? 1 : 0;
-    if (conv_wino4_fits(k)) return conv2d_wino4(k, s);
+    if (conv_wino4_fits(k))       // 0x400000: the experimental half-position kernel (A/B only)
+      return (d.tile & 0x400000) ? conv2d_wino4h(k, s) : conv2d_wino4(k, s);
     // tensors beyond the kernel's 1 GiB offset scheme (B > 334 at 224x224): the direct kernel on
     // the untransformed weights, which every layer carries -- slower, same convolution
     k.wgt2 = nullptr;
