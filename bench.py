@@ -15,10 +15,13 @@ scaling: 64 images per GPU) and the predicted betas are all-gathered with RCCL o
 a side stream (joined when the next step issues its gather, shapy_amd/parallel.py).
 
 Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
-  roofline      the roofline of the dominant kernel family.  regressor: MFMA, algorithmic conv
-                FLOPs (2 x 18,466,524,160 MAC per image) / time of the backbone
-                call, measured with HIP events on the launch stream inside the timed loop, peak
-                157.3 TFLOP/s (f32 MFMA, dense).  measurements / smplx: HBM, algorithmic bytes
+  roofline      the roofline of the dominant kernel family.  regressor: MFMA; `achieved` = the
+                FLOPs the matrix cores EXECUTE (Winograd layers: 36 products per 4x4 tile / 16 per
+                2x2 tile and channel pair) / time of the backbone call, measured with HIP events
+                on the launch stream inside the timed loop, peak 157.3 TFLOP/s (f32 MFMA, dense),
+                so frac <= 1 by construction; the direct-convolution-equivalent rate (2 x
+                18,466,524,160 MAC per image) is `algorithmic_equiv_tflops`.
+                measurements / smplx / bvh: HBM, algorithmic bytes
                 (376.6 KB per mesh; 65.4 MB constants + 254.4 KB per body) / time
                 of the launch group, peak 8 TB/s
   parity        (regressor) error of the LAST timed batch against the CPU oracle, computed after
@@ -415,7 +418,13 @@ def run_regressor(args, rank, world, local_rank):
 
     backbone_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     flop_img = conv_flop_per_image(net, args.size)
-    achieved = flop_img * B / (backbone_ms * 1e-3) / 1e12
+    algorithmic = flop_img * B / (backbone_ms * 1e-3) / 1e12
+    # `achieved` = FLOPs the matrix cores EXECUTE / backbone time, so that frac <= 1 by
+    # construction: the Winograd layers execute 2.25x (F(2x2)) / 4x (F(4x4)) fewer multiplies than
+    # the direct convolution they compute.  The direct-convolution-equivalent rate (SURVEY.md 8d:
+    # 36.933 GFLOP per image) is reported next to it as `algorithmic_equiv_tflops`.
+    exec_img = executed_mfma_flop_per_image(net, args.size) if args.dtype == 'f32' else flop_img
+    achieved = exec_img * B / (backbone_ms * 1e-3) / 1e12
     # f32x6 issues 6 bf16 MFMAs per float32 multiply-add: its matrix-core roof in algorithmic
     # (float32) FLOP/s is the dense bf16 peak / 6
     peak = {'f32': F32_MFMA_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS,
@@ -427,14 +436,14 @@ def run_regressor(args, rank, world, local_rank):
     algo = getattr(net.backbone, 'conv_algo', 'direct')
     if args.dtype == 'f32' and algo == 'winograd4':
         kernel += f' + conv_wino4_kernel (Winograd F(4x4,3x3), maps >= {net.backbone.wino4_min_hw} ' \
-                  'px) + conv_wino_kernel (F(2x2,3x3), the other 3x3 stride-1 layers); achieved ' \
-                  'counts the ALGORITHMIC direct-conv FLOPs'
+                  'px) + conv_wino_kernel (F(2x2,3x3), the other 3x3 stride-1 layers)'
     elif args.dtype == 'f32' and algo != 'direct':
         kernel += f' + conv_wino_kernel (Winograd F(2x2,3x3) for the 3x3 stride-1 layers, ' \
-                  f'algo={algo}; achieved counts the ALGORITHMIC direct-conv FLOPs)'
+                  f'algo={algo})'
     # HBM bytes per launch group (one backbone forward) from the committed PMC passes, gfx950
     # FETCH x2 correction applied
     traffic = pmc_traffic(B, args.size, args.dtype, algo)
+    n_launch = sum(1 for o in _f32_plan(net, args.size).ops if o['type'] != 2) if args.dtype == 'f32' else 330
     traffic_other = None
     if traffic is None:      # no PMC pass of THIS algorithm yet: `traffic` stays null; the last
         # measured build of the same workload is quoted as context, labelled with its algorithm
@@ -477,19 +486,16 @@ def run_regressor(args, rank, world, local_rank):
                          'other_build': traffic_other},
                      'peak_sustained_measured': {'f32': 141.0, 'bf16': 1410.0,
                                                  'f32x6': 1410.0 / 6.0}[args.dtype],
-                     'kernel': kernel + ', 330 launches per backbone forward',
-                     'flop_per_launch_group': flop_img * B,
-                     'ms_per_launch_group': backbone_ms},
+                     'kernel': kernel + f', {n_launch} launches per backbone forward',
+                     'flop_per_launch_group': exec_img * B,
+                     'ms_per_launch_group': backbone_ms,
+                     'achieved_counts': 'FLOPs issued to the matrix cores (direct layers: 2 x MAC; '
+                                        'Winograd layers: 16 products per 2x2 tile / 36 per 4x4 tile '
+                                        'and channel pair, whole tiles) / backbone time (HIP events)',
+                     'algorithmic_equiv_tflops': algorithmic,
+                     'algorithmic_equiv_frac_of_peak': algorithmic / peak,
+                     'algorithmic_flop_per_launch_group': flop_img * B},
     }
-    if args.dtype == 'f32':
-        # `achieved` counts the direct-convolution FLOPs the layers DEFINE (the contract's
-        # algorithmic work); the Winograd layers execute 2.25x / 4x fewer multiplies, so with them
-        # `frac` can exceed 1.  What the matrix cores themselves execute, for comparison:
-        ex = executed_mfma_flop_per_image(net, args.size) * B / (backbone_ms * 1e-3) / 1e12
-        res['roofline']['executed_mfma'] = {
-            'tflops': ex, 'frac_of_peak': ex / peak,
-            'note': 'FLOPs issued to the f32 matrix cores (Winograd layers: 16 products per 2x2 '
-                    'tile, 36 per 4x4 tile and channel pair) / backbone time'}
     if world > 1:
         res['rccl_ranks'] = world
         res['per_rank'] = {'images_per_sec': per_rank,

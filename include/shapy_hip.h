@@ -99,8 +99,7 @@ typedef struct ShapyConv {
                          never Winograd, 0x4000 / 0x8000 Winograd tile groups, 0x20000 Winograd K
                          loop chunk by chunk, 0x40000 / 0x80000 three / one chunk(s) of loads in
                          flight.  Speed only: every setting computes the same convolution.
-                         (0x200000: F(4x4) kernel with its 12-chunk loop unrolled, Cin = 192;
-                         0x400000: the experimental position-split F(4x4) kernel, A/B only.)
+                         (0x200000: F(4x4) kernel with its 12-chunk loop unrolled, Cin = 192.)
                          One bit describes DATA instead: SHAPY_TILE_WINO4 (0x100000) says that
                          wgt_wino holds F(4x4,3x3) filters (below).                             */
   int32_t dtype;      /* storage type of in / wgt / res / out: SHAPY_DTYPE_F32 (f32 MFMA, exact

@@ -20,6 +20,8 @@
 // (tools/lds_swizzle_check.py checks the gfx950 lane-group table exhaustively).
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "conv_common.h"
 
 namespace shapy {
@@ -363,13 +365,22 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   // the host's policy again: HighResolutionNet.conv_algo = 'winograd4') -- there is no other
   // kernel for that layout, so an ineligible layer is an error, not a fallback
   if (d.tile & 0x100000) {
-    if (d.dtype != SHAPY_DTYPE_F32 || !conv_wino_eligible(k) || k.Cout % 48) return SHAPY_EINVAL;
     k.w4_unroll12 = (d.tile & 0x200000) ? 1 : 0;
-    if (conv_wino4_fits(k))       // 0x400000: the experimental half-position kernel (A/B only)
-      return (d.tile & 0x400000) ? conv2d_wino4h(k, s) : conv2d_wino4(k, s);
+    if (conv_wino4_fits(k)) {      // (size limits first: conv_wino_eligible also refuses > 2 GiB)
+      if (d.dtype != SHAPY_DTYPE_F32 || !conv_wino_eligible(k)) return SHAPY_EINVAL;
+      return conv2d_wino4(k, s);
+    }
+    if (d.dtype != SHAPY_DTYPE_F32 || k.Cout % 48) return SHAPY_EINVAL;
     // tensors beyond the kernel's 1 GiB offset scheme (B > 334 at 224x224): the direct kernel on
     // the untransformed weights, which every layer carries -- slower, same convolution
     k.wgt2 = nullptr;
+    static bool warned = false;        // once per process: a 1.7x per-layer perf cliff must not be silent
+    if (!warned) {
+      warned = true;
+      fprintf(stderr, "shapy: F(4x4) Winograd layer %dx%d %d->%d at M=%d exceeds the kernel's 1 GiB "
+                      "addressing; this and larger layers run the direct kernel (slower, same result)\n",
+              k.Hi, k.Wi, k.Cin, k.Cout, k.M);
+    }
   }
   if (d.dtype == SHAPY_DTYPE_F32 && !(d.tile & 0x2000) && conv_wino_eligible(k))
     return conv2d_wino(k, (d.tile & 0x4000) ? 1 : (d.tile & 0x8000) ? 2 : 0, s);

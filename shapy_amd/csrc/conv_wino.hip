@@ -367,7 +367,10 @@ bool conv_wino_eligible(const ConvK &k) {
   return k.wgt2 != nullptr && k.ks == 3 && k.stride == 1 && k.pad == 1 && k.ups == 1 &&
          k.Cin % 16 == 0 && (k.Cout % 48 == 0 || k.Cout % 64 == 0) && k.vec4 && k.Ho == k.Hi &&
          k.Wo == k.Wi &&
-         (!k.bias || ((uintptr_t)k.bias & 15) == 0);
+         (!k.bias || ((uintptr_t)k.bias & 15) == 0) &&
+         // the kernel addresses `res` (and the F(4x4) fallback lands here too) with 32-bit byte
+         // offsets against a 2 GiB buffer resource: larger extents take the direct kernel
+         4ull * k.M * k.out_ld < 0x7fffffffull && (!k.res || 4ull * k.M * k.res_ld < 0x7fffffffull);
 }
 
 // tm: 0 = choose, 1 / 2 = tile groups (16 tiles each) per workgroup.  Two groups halve the

@@ -21,6 +21,8 @@
 // (SAT tolerance tests, barycentric range tests) is bit-identical with the CPU oracle.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "tri_tri.h"
 
 namespace shapy {
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
   }
   __syncthreads();
   M2_STAMP(9);
-  // ---- rank sort of the slots [0, nn) by (x, z), ties by slot; +inf holes sink to the end ----
+  // ---- rank sort of the slots [0, nn) by (x, z), ties by (y, slot); +inf holes sink to the end ----
   // one order-preserving 64-bit key per point (parked in the chain buffers, which are not
   // needed yet): a comparison is two integer compares instead of a lexicographic float cascade
   constexpr int EPL = 16;                              // slots per lane (NP <= 1024)
@@ -404,16 +406,23 @@ __global__ __launch_bounds__(64, 4) void measure_hull2_kernel(
       ke[r] = in ? key[e] : ~0ull;
       rank[r] = 0;
     }
+    // ties on (x, z) -- duplicated contour points, whose y may differ by an ulp -- are ordered by
+    // (y, slot): the compaction below keeps the FIRST of a run, i.e. the lowest y, so the result
+    // is a function of the point SET and not of the order in which the scan kernel's atomics
+    // handed out the slots (equal (x, y, z) triples are interchangeable)
+    auto before = [&](unsigned long long kj, unsigned long long ke_, int j, int e, float ye) {
+      if (kj != ke_) return kj < ke_;
+      const unsigned yj = ord(py[j]), yo = ord(ye);
+      return yj < yo || (yj == yo && j < e);
+    };
     for (int j = 0; j < nn; j += 4) {
       const unsigned long long k0 = key[j], k1 = key[j + 1], k2 = key[j + 2], k3 = key[j + 3];
 #pragma unroll
       for (int r = 0; r < EPL; ++r) {
         if (r < per) {
           const int e = lane + 64 * r;
-          rank[r] += (int)(k0 < ke[r] || (k0 == ke[r] && j < e)) +
-                     (int)(k1 < ke[r] || (k1 == ke[r] && j + 1 < e)) +
-                     (int)(k2 < ke[r] || (k2 == ke[r] && j + 2 < e)) +
-                     (int)(k3 < ke[r] || (k3 == ke[r] && j + 3 < e));
+          rank[r] += (int)before(k0, ke[r], j, e, ey[r]) + (int)before(k1, ke[r], j + 1, e, ey[r]) +
+                     (int)before(k2, ke[r], j + 2, e, ey[r]) + (int)before(k3, ke[r], j + 3, e, ey[r]);
         }
       }
     }
@@ -607,12 +616,20 @@ extern "C" int shapy_body_measure_f32(const float *v_shaped, const int32_t *face
   int S = 1;
   if (measure_staged(V)) {
     const size_t dyn = (size_t)V * 12 + 32;
-    static bool attr_set = false;       // > 64 KB of dynamic LDS must be opted into once
-    if (!attr_set) {
-      SHAPY_HIP_TRY(hipFuncSetAttribute((const void *)measure_scan2_kernel<true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        M2_LDS_TOTAL - M2_STATIC_LDS));
-      attr_set = true;
+    // > 64 KB of dynamic LDS must be opted into -- PER DEVICE (the attribute lives in the
+    // device's copy of the function): a bitmask of the devices done, under a mutex
+    {
+      static std::mutex mu;
+      static unsigned long long done = 0;
+      int dev = 0;
+      SHAPY_HIP_TRY(hipGetDevice(&dev));
+      std::lock_guard<std::mutex> lk(mu);
+      if (dev < 0 || dev >= 64 || !(done >> dev & 1ull)) {
+        SHAPY_HIP_TRY(hipFuncSetAttribute((const void *)measure_scan2_kernel<true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          M2_LDS_TOTAL - M2_STATIC_LDS));
+        if (dev >= 0 && dev < 64) done |= 1ull << dev;
+      }
     }
     // small batches: several workgroups per mesh (each stages the whole vertex array -- the
     // repeats hit L2 -- and scans a slice of the faces) so that the chip is not left idle

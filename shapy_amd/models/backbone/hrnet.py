@@ -523,7 +523,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                  res_ld=(res_ld or (res.C if res is not None else 0)), res_coff=res_coff,
                  relu=int(relu), ups=ups,
                  tile=_lib.TILES[ov.get(name, 'auto')] | self.tile_flags | wino_flag,
-                 wgt_off=P.add_conv_weights(w), bias_off=P.add_weights(b), wino_off=wino_off)
+                 wgt_off=P.add_conv_weights(w), bias_off=P.add_weights(b), wino_off=wino_off,
+                 name=name)
             return outb, Ho, Wo
 
         # stem (hrnet.py:427-432)

@@ -168,7 +168,13 @@ class HMRLikeRegressor(nn.Module):
         lay = None
         dec = [n for n in self.param_names if hasattr(self, f'{n}_decoder')]
         if (self.pose_last_stage and dec == ['global_rot', 'body_pose']
-                and {'betas', 'camera'} <= set(self.param_names)
+                # ONLY these four: anything else in param_names (expression, jaw / hand poses,
+                # transl) is an argument of self.model(**merged_params) on the generic path and
+                # would be dropped silently here; the betas slice must be the model's own width
+                # (the generic path raises on a mismatch instead of truncating)
+                and set(self.param_names) == {'global_rot', 'body_pose', 'betas', 'camera'}
+                and self._slices['betas'][1] - self._slices['betas'][0]
+                == min(self.model.num_betas, self.model.SHAPE_SPACE_DIM)
                 and self._slices['global_rot'][1] == self._slices['body_pose'][0]
                 and hasattr(self.model, 'forward_prepared')):
             g, b = self.global_rot_decoder, self.body_pose_decoder
@@ -199,8 +205,9 @@ class HMRLikeRegressor(nn.Module):
         coeffs = torch.empty(B, dm['NBpad'], **f32)
         cam = torch.empty(B, 3, **f32)
         b0, b1 = lay['betas']
+        assert b1 - b0 == dm['nb'], (b0, b1, dm['nb'])     # _fast_head_layout checked it
         _lib.check(_lib.load().shapy_head_prepare_f32(
-            _lib.ptr(out3), S, B, P, lay['pose_off'], nj, lay['pose_type'], b0, min(b1 - b0, dm['nb']),
+            _lib.ptr(out3), S, B, P, lay['pose_off'], nj, lay['pose_type'], b0, b1 - b0,
             dm['NBpad'], lay['cam_off'], _lib.ptr(rot_all), _lib.ptr(coeffs), _lib.ptr(cam),
             _lib.current_stream()), 'shapy_head_prepare_f32')
         param_dicts = []

@@ -216,6 +216,26 @@ def test_weight_caches_are_keyed_on_parameter_versions(hrnet):
     assert hrnet.__dict__['_ver_tensors'] is None and hrnet._engine == {}
 
 
+def test_weight_cache_key_sees_replaced_parameters_but_not_dot_data_edits(hrnet):
+    """ADVICE r2: replacing a Parameter object moves the key (registration epoch + tensor ids);
+    an edit through ``p.data`` does NOT bump ``p._version`` -- documented: it needs invalidate()."""
+    import torch.nn as nn
+    v0 = hrnet._weights_version()
+    old = hrnet.conv2.weight
+    hrnet.conv2.weight = nn.Parameter(old.detach().clone())      # same values, new object
+    v1 = hrnet._weights_version()
+    assert v1 != v0
+    assert any(t is hrnet.conv2.weight for t in hrnet.__dict__['_ver_tensors'])   # list re-walked
+    hrnet.conv2.weight = old
+    # the documented blind spot: .data has its own version counter
+    v2 = hrnet._weights_version()
+    hrnet.conv1.weight.data.mul_(1.0)
+    assert hrnet._weights_version() == v2
+    hrnet._engine['sentinel'] = 1
+    hrnet.invalidate()                                           # what the docs prescribe after it
+    assert hrnet._engine == {}
+
+
 def test_winograd_plan_covers_the_3x3_stride1_layers(hrnet):
     from shapy_amd.utils import winograd
     hrnet.conv_algo = 'winograd'

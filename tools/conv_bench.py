@@ -69,7 +69,7 @@ def main():
         wu = wu4 = None
         for tile in args.tiles.split(','):
             d = _lib.ShapyConv()
-            if tile in ('wino4', 'wino4u12', 'wino4h'):                       # Winograd F(4x4,3x3) (conv_wino4.hip)
+            if tile in ('wino4', 'wino4u12'):                       # Winograd F(4x4,3x3) (conv_wino4.hip)
                 from shapy_amd.utils import winograd
                 if args.dtype != 'f32' or not winograd.eligible4(ks, st, pad, Cin, Cout, ups) \
                         or min(Hi, Wi) < args.wino4_min_hw:
@@ -93,8 +93,7 @@ def main():
             d.out_ld = Cout; d.out_coff = 0; d.res_ld = Cout if has_res else 0; d.res_coff = 0
             d.relu = int(relu); d.ups = ups; d.tile = {'wino': 0, 'wino1': 0x4000, 'wino2': 0x8000, 'winochunk': 0x20000,
                                                      'wino4': _lib.TILE_WINO4,
-                                                     'wino4u12': _lib.TILE_WINO4 | _lib.TILE_WINO4_UNROLL12,
-                                                     'wino4h': _lib.TILE_WINO4 | _lib.TILE_WINO4_HALF}[tile] if tile.startswith('wino') else _lib.TILES[tile]
+                                                     'wino4u12': _lib.TILE_WINO4 | _lib.TILE_WINO4_UNROLL12}[tile] if tile.startswith('wino') else _lib.TILES[tile]
             d.dtype = {'f32': _lib.DTYPE_F32, 'bf16': _lib.DTYPE_BF16, 'f32x6': _lib.DTYPE_F32X6}[args.dtype]
             rc = 0
             for _ in range(2):

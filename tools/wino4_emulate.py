@@ -144,129 +144,6 @@ def emulate_workgroup(x, u, bias, res, relu, out, wg_m, wg_n, out_ld, out_coff, 
                             outf[oo // 4] = v
 
 
-def emulate_workgroup_half(x, u, bias, res, relu, out, wg_m, wg_n, out_ld, out_coff, res_ld, res_coff):
-    """csrc/conv_wino4h.hip (experimental): two staging waves (lane = (tile, channel pair)), six
-    multiplying waves (n tile = wave % 3, position rows 3 h .. 3 h + 2 with h = wave // 3), partial
-    output transforms, exchange of two tiles' partials with the partner wave, finish."""
-    B, H, W, in_ld = x.shape
-    Cin, Cout = in_ld, u.shape[2]
-    TW, TH = (W + 3) // 4, (H + 3) // 4
-    T = B * TH * TW
-    CC = Cin // 16
-    m_blk, n_blk = wg_m * 16, wg_n * 48
-    xin = x.reshape(-1)
-    in_bytes = xin.size * 4
-    uflat = u.reshape(-1)
-    u_bytes = uflat.size * 4
-    lds = np.zeros(2 * LDS_V // 4, f32)
-    acc = np.zeros((6, 64, 18, 4), np.float64)          # wave, lane, local position, r
-    pix_stride = in_ld * 4
-    for cc in range(CC):
-        for q in range(2):                              # staging waves 6, 7
-            for lane in range(64):
-                tile_s, c2 = q * 8 + (lane >> 3), lane & 7
-                tile = m_blk + tile_s
-                live = tile < T
-                tt = tile if live else 0
-                tx, tq = tt % TW, tt // TW
-                ty, b = tq % TH, tq // TH
-                y0, x0 = 4 * ty - 1, 4 * tx - 1
-                row_off = [((b * H + y0 + i) * W * pix_stride + c2 * 8) if (live and 0 <= y0 + i < H)
-                           else BAD for i in range(6)]
-                col_off = [(x0 + j) * pix_stride if 0 <= x0 + j < W else BAD for j in range(6)]
-                raw = [[buf_load(xin, in_bytes, row_off[i] + col_off[j] + cc * 64, 8)
-                        for j in range(6)] for i in range(6)]
-                for i in range(6):
-                    raw[i] = bt6(raw[i])
-                st_off = tile_s * 64 + ((((c2 >> 1) ^ tile_s ^ (tile_s >> 1)) & 3) << 4) + (c2 & 1) * 8
-                for j in range(6):
-                    v = bt6([raw[i][j] for i in range(6)])
-                    for i in range(6):
-                        o = ((cc & 1) * LDS_V + st_off + (6 * i + j) * PSTR) // 4
-                        lds[o:o + 2] = v[i]
-        for wave in range(6):
-            jn, h = wave % 3, wave // 3
-            n0 = n_blk + 16 * jn
-            AF = np.zeros((18, 64, 4), f32)
-            BF = np.zeros((18, 64, 4), f32)
-            u_pos, u_chunk = CC * Cout * 64, Cout * 64
-            for lane in range(64):
-                g, l15 = lane >> 4, lane & 15
-                frag_off = l15 * 64 + (((g ^ l15 ^ (l15 >> 1)) & 3) << 4) + 18 * h * PSTR
-                u_lane = ((n0 + l15) * 16 + 4 * g) * 4
-                for pl in range(18):
-                    o = ((cc & 1) * LDS_V + frag_off + pl * PSTR) // 4
-                    AF[pl, lane] = lds[o:o + 4]
-                    BF[pl, lane] = buf_load(uflat, u_bytes,
-                                            u_lane + 18 * h * u_pos + pl * u_pos + cc * u_chunk, 16)
-            A = AF.reshape(18, 4, 16, 4).astype(np.float64)
-            Bm = BF.reshape(18, 4, 16, 4).astype(np.float64)
-            D = np.einsum('pgik,pgjk->pij', A, Bm)
-            for lane in range(64):
-                g, l15 = lane >> 4, lane & 15
-                for r in range(4):
-                    acc[wave, lane, :, r] += D[:, 4 * g + r, l15]
-    # ---- partial output transforms + exchange (floats; receiver region: wave * 2048) ----
-    xch = np.full(6 * 2048, np.nan, f32)
-    part = np.zeros((6, 64, 4, 16), f32)
-    for wave in range(6):
-        h = wave // 3
-        for lane in range(64):
-            for r in range(4):
-                m = acc[wave, lane, :, r].astype(f32).reshape(3, 6)
-                s = [at6(list(m[i])) for i in range(3)]
-                for bb in range(4):
-                    if h == 0:
-                        s12, d12 = s[1][bb] + s[2][bb], s[1][bb] - s[2][bb]
-                        vals = (s[0][bb] + s12, d12, s12, d12)
-                    else:
-                        sm, df = s[0][bb] + s[1][bb], s[0][bb] - s[1][bb]
-                        vals = (sm, f32(2) * df, f32(4) * sm, f32(8) * df + s[2][bb])
-                    for a in range(4):
-                        part[wave, lane, r, 4 * a + bb] = vals[a]
-            partner = wave + 3 if h == 0 else wave - 3
-            for rl in range(2):
-                for v in range(16):
-                    give = part[wave, lane, 2 + rl, v] if h == 0 else part[wave, lane, rl, v]
-                    o = partner * 2048 + (rl * 16 + v) * 64 + lane
-                    assert np.isnan(xch[o]), 'exchange slot written twice'
-                    xch[o] = give
-    assert not np.isnan(xch).any(), 'exchange slot never written'
-    outf = out.reshape(-1)
-    for wave in range(6):
-        jn, h = wave % 3, wave // 3
-        n0 = n_blk + 16 * jn
-        for lane in range(64):
-            g, l15 = lane >> 4, lane & 15
-            col = n0 + l15
-            for rl in range(2):
-                tile = m_blk + 4 * g + 2 * h + rl
-                live = tile < T
-                tt = tile if live else 0
-                tx, tq = tt % TW, tt // TW
-                ty, b = tq % TH, tq // TH
-                pix0 = (b * H + 4 * ty) * W + 4 * tx
-                obase = (pix0 * out_ld + out_coff + col) * 4 if live else BAD
-                rbase = (pix0 * res_ld + res_coff + col) * 4 if (live and res is not None) else BAD
-                nrow, ncol = H - 4 * ty, W - 4 * tx
-                for a in range(4):
-                    for bb in range(4):
-                        ok = a < nrow and bb < ncol
-                        own = part[wave, lane, rl if h == 0 else 2 + rl, 4 * a + bb]
-                        got = xch[wave * 2048 + (rl * 16 + 4 * a + bb) * 64 + lane]
-                        rv = f32(0)
-                        if res is not None:
-                            ro = (rbase if ok else BAD) + (a * W + bb) * res_ld * 4
-                            rv = buf_load(res.reshape(-1), BAD, ro, 4)[0] if ro < BAD else f32(0)
-                        v = ((own + got) + bias[col]) + rv
-                        if relu:
-                            v = max(v, f32(0))
-                        oo = (obase if ok else BAD) + (a * W + bb) * out_ld * 4
-                        if oo < BAD:
-                            assert outf[oo // 4] != outf[oo // 4], 'element written twice'
-                            outf[oo // 4] = v
-
-
 def direct_conv(x, w, bias):
     B, H, W, C = x.shape
     xp = np.zeros((B, H + 2, W + 2, C))
@@ -278,7 +155,7 @@ def direct_conv(x, w, bias):
     return ref + bias
 
 
-def check(B, H, W, Cin, Cout, with_res, relu, coff=0, seed=0, half=False):
+def check(B, H, W, Cin, Cout, with_res, relu, coff=0, seed=0):
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((B, H, W, Cin)).astype(f32)
     w = (rng.standard_normal((Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(f32)
@@ -291,7 +168,7 @@ def check(B, H, W, Cin, Cout, with_res, relu, coff=0, seed=0, half=False):
     nby, nbx = (B * TH * TW + 15) // 16, Cout // 48
     for m in range(nby):
         for n in range(nbx):
-            (emulate_workgroup_half if half else emulate_workgroup)(
+            emulate_workgroup(
                 x, u, bias, res, relu, out, m, n, out_ld, coff, Cout, 0)
     ref = direct_conv(x, w, bias)
     if with_res:
@@ -302,7 +179,7 @@ def check(B, H, W, Cin, Cout, with_res, relu, coff=0, seed=0, half=False):
     assert not np.isnan(got).any(), 'unwritten outputs'
     assert coff == 0 or np.isnan(out[..., :coff]).all(), 'wrote outside its channel slice'
     err = np.abs(got - ref).max()
-    print(f'{"half-position kernel " if half else ""}B={B} {H}x{W} {Cin}->{Cout} res={with_res} '
+    print(f'B={B} {H}x{W} {Cin}->{Cout} res={with_res} '
           f'relu={relu} coff={coff}: '
           f'{nby * nbx} workgroups, max err {err:.2e}')
     assert err < 2e-5, err
@@ -361,8 +238,4 @@ if __name__ == '__main__':
     check(2, 12, 20, 48, 48, True, True)                # 30 tiles: two workgroups, 3 chunks
     check(1, 7, 9, 32, 96, True, False)                 # partial edge tiles, two N tiles
     check(1, 14, 14, 16, 48, False, False, coff=16)     # concat-style channel offset
-    for args in ((1, 8, 8, 16, 48, False, True), (2, 12, 20, 48, 48, True, True),
-                 (1, 7, 9, 32, 96, True, False)):
-        check(*args, half=True)                          # csrc/conv_wino4h.hip (experimental)
-    check(1, 14, 14, 16, 48, False, False, coff=16, half=True)
     print('emulation OK')
