@@ -7,6 +7,7 @@ SMPL-X + virtual measurements) on synthetic 224x224 crops, batch 64 per GPU, flo
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --workload measurements --meshes 1000   # BASELINE configs[3]
     python bench.py --workload smplx --batch 64             # SMPL-X layer alone (LBS evidence)
+    python bench.py --workload bvh --meshes 1000            # LBVH path of the intersection op
 
 One "step" of the default workload = one full forward of the regressor on one batch that is
 already resident in HBM (BASELINE.json configs[1]: "HRNet-W48 + SMPL-X head, random-init
@@ -186,17 +187,69 @@ def self_spawn(n):
     return subprocess.call(cmd, env=env)
 
 
+STUB = {'on': False}      # --cpu-stub (tests/test_host_cpu.py): gloo ranks, stub forward, no GPU
+
+
 def barrier():
     """RCCL barrier on this rank's own GPU (named explicitly: no device guessing)."""
     import torch
     import torch.distributed as dist
-    dist.barrier(device_ids=[torch.cuda.current_device()])
+    if STUB['on']:
+        dist.barrier()
+    else:
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+
+
+def device_sync():
+    import torch
+    if not STUB['on']:
+        torch.cuda.synchronize()
+
+
+class _HostEvent:
+    """perf_counter stand-in for a HIP event (--cpu-stub only)."""
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
 
 
 def hip_events(n):
     import torch
+    if STUB['on']:
+        return [_HostEvent() for _ in range(n)], [_HostEvent() for _ in range(n)]
     return ([torch.cuda.Event(enable_timing=True) for _ in range(n)],
             [torch.cuda.Event(enable_timing=True) for _ in range(n)])
+
+
+def make_stub_network(size):
+    """--cpu-stub: a CPU module with the regressor's interface (backbone hook points, output dict
+    with stage_02.betas) whose "betas" are a fixed linear function of the images -- enough to run
+    the whole N-rank control flow of this file (self-spawn, rendezvous, barriers, the deferred
+    all-gather, max-over-ranks timing, the JSON line) on the gloo backend without a GPU."""
+    import torch
+    import torch.nn as nn
+
+    class _Backbone(nn.Module):
+        conv_algo, use_graph, graph_max_batch, wino4_min_hw = 'stub', False, 0, 0
+        multi_stream, compute_dtype, tile_flags, _engine = False, 'f32', 0, {}
+
+        def forward(self, x):
+            return {'concat': x.mean(dim=(2, 3))}
+
+    class _Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = _Backbone()
+            g = torch.Generator().manual_seed(0)
+            self.register_buffer('w', torch.randn(3, 10, generator=g))
+
+        def forward(self, x, targets=None):
+            feat = self.backbone(x)['concat']
+            return {'stage_02': {'betas': feat @ self.w}, 'features': feat}
+    return _Net().eval()
 
 
 def config4_meshes(n, seed=0):
@@ -293,6 +346,80 @@ def run_measurements(args, rank, world):
     return res
 
 
+def run_bvh(args, rank, world):
+    """The LBVH path of the intersection operator (csrc/bvh.hip: build / wave-cooperative
+    traverse / sort-hits), which BASELINE configs[3] itself does not exercise (its 2-triangle plane
+    queries take the scan path): body-vs-body queries -- `--query-faces` triangles of the NEXT
+    config-4 body against all 20,908 triangles of this one, `--meshes` pairs per GPU.
+    Counterpart of mesh_mesh_intersect_cuda_op.cu:823-967 (build), :520-609 (traverse)."""
+    import numpy as np
+    import torch
+    import mesh_mesh_intersect_cuda as mmi
+    faces_np, v_np = config4_meshes(args.meshes, seed=rank)
+    Q, mc = args.query_faces, args.max_collisions
+    tris = torch.from_numpy(v_np).cuda()[:, torch.from_numpy(faces_np).cuda().long()].contiguous()
+    q0 = 3000
+    query = torch.roll(tris, -1, 0)[:, q0:q0 + Q].contiguous()       # the next body's triangles
+    B, F = tris.shape[:2]
+    for _ in range(args.warmup):
+        f, b = mmi.mesh_to_mesh_forward(query, tris, max_collisions=mc)
+    ev0, ev1 = hip_events(args.steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record()
+        f, b = mmi.mesh_to_mesh_forward(query, tris, max_collisions=mc)
+        ev1[i].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = float(np.mean([a.elapsed_time(b_) for a, b_ in zip(ev0, ev1)]))
+    overflow = int(mmi.mesh_to_mesh_forward.last_overflow.item())
+    hits = int((f >= 0).sum().item())
+    in_bytes = (F + Q) * 36
+    out_bytes = Q * mc * (8 + 24)
+    nbytes = (in_bytes + out_bytes) * B
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    res = {
+        'metric': 'mesh pairs/sec, mesh_to_mesh_forward through the LBVH (build + traverse + '
+                  'sort hits); faces / barycentrics bit-exact vs CPU oracle',
+        'value': B * args.steps / dt, 'unit': 'mesh pairs/sec', 'n_gpus': 1, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'LBVH intersection: {Q} query triangles (faces {q0}..{q0 + Q} of the '
+                               f'next body) vs {F} target triangles, {B} config-4 body pairs, '
+                               f'max_collisions {mc}', 'pairs': B, 'query_faces': Q,
+                   'max_collisions': mc},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'kernel': 'bvh_build_kernel + bvh_traverse_kernel + bvh_sort_hits_kernel (one '
+                               'launch group; the time is the whole group incl. the output memsets)',
+                     'bytes_per_launch_group': nbytes, 'ms_per_launch_group': ms,
+                     'algorithmic_bytes_per_pair': {
+                         'target_triangles_read': F * 36, 'query_triangles_read': Q * 36,
+                         'faces_int64_and_bcs_written': out_bytes,
+                         'note': 'operator contract: [B,F,3,3] + [B,Q,3,3] in, [B,Q*mc] int64 + '
+                                 '[B,Q*mc,2,3] f32 out; the tree itself (keys, nodes, boxes: ~2.5 '
+                                 'MB per mesh, SURVEY.md 8d) is internal traffic, not counted'}},
+        'hits_per_pair': hits / B, 'overflowed_hits': overflow,
+    }
+    if not args.no_cpu_baseline:
+        from oracle import measure as om
+        n = min(B, 3)
+        qn, tn = query[:n].cpu().numpy(), tris[:n].cpu().numpy()
+        t0 = time.perf_counter()
+        f_ref, b_ref = om.mesh_to_mesh_forward(qn, tn, mc)
+        dtc = time.perf_counter() - t0
+        res['cpu_baseline'] = {'value': n / dtc, 'unit': 'mesh pairs/sec', 'cores': 1, 'kind': 'port',
+                               'cpu_model': cpu_model(),
+                               'sample': f'{n} pairs through the C oracle (brute force, {Q} x {F} '
+                                         f'SAT tests each, 1 thread) in {dtc:.1f} s'}
+        res['parity'] = {'n_pairs': n, 'reference': 'C oracle (oracle/mesh_intersect.c)',
+                         'faces_equal': bool(np.array_equal(f[:n].cpu().numpy(), f_ref)),
+                         'bcs_equal': bool(np.array_equal(b[:n].cpu().numpy(), b_ref)),
+                         'oracle_dropped': int(om.mesh_to_mesh_forward.last_dropped)}
+    return res
+
+
 def run_smplx(args, rank, world):
     """The SMPL-X layer alone (BASELINE configs[0] shape at --batch bodies): blend shapes,
     joint regression, pose chain, skinning, landmarks.  HBM roofline per SURVEY.md 8(d)."""
@@ -343,6 +470,9 @@ def run_smplx(args, rank, world):
 
 
 def run_regressor(args, rank, world, local_rank):
+    """Returns (json dict or None, finish): `finish(res)` adds the rank-0 CPU oracle fields
+    (cpu_baseline, parity) and is called by main() AFTER the process group is torn down, so no
+    rank sits in a collective while rank 0 spends ~15 s on the host."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -350,25 +480,32 @@ def run_regressor(args, rank, world, local_rank):
     from shapy_amd.utils import synthetic as syn
     from shapy_amd import parallel
 
-    net, _ = ge.make_network(model_folder=f'/tmp/shapy_synth_models_r{local_rank}' if world > 1
-                             else '/tmp/shapy_synth_models')
-    net.backbone.multi_stream = not args.single_stream
-    net.backbone.compute_dtype = args.dtype
-    net.backbone.use_graph = {'auto': 'auto', 'on': True, 'off': False}[args.graph]
-    if args.algo:
-        net.backbone.conv_algo = args.algo
-    if args.wino4_min_hw:
-        net.backbone.wino4_min_hw = args.wino4_min_hw
-    if args.tile_flags:
-        net.backbone.tile_flags = int(args.tile_flags, 0)
+    stub = STUB['on']
+    dev = 'cpu' if stub else 'cuda'
+    if stub:
+        net = make_stub_network(args.size)
+    else:
+        net, _ = ge.make_network(model_folder=f'/tmp/shapy_synth_models_r{local_rank}' if world > 1
+                                 else '/tmp/shapy_synth_models')
+        net.backbone.multi_stream = not args.single_stream
+        net.backbone.compute_dtype = args.dtype
+        net.backbone.use_graph = {'auto': 'auto', 'on': True, 'off': False}[args.graph]
+        if args.algo:
+            net.backbone.conv_algo = args.algo
+        if args.wino4_min_hw:
+            net.backbone.wino4_min_hw = args.wino4_min_hw
+        if args.tile_flags:
+            net.backbone.tile_flags = int(args.tile_flags, 0)
     B = args.batch
     # distinct synthetic images per rank (global batch = world * B), resident in HBM
     x_np = syn.synthetic_images(B, args.size, 100 + rank)
-    x = torch.from_numpy(x_np).cuda()
+    x = torch.from_numpy(x_np).to(dev)
     gatherer = parallel.BetasGatherer(world)
     # the timed region includes the D2H of the betas (async copy into pinned host
     # memory on the compute stream; the closing synchronize covers the last one)
-    betas_host = torch.empty(B, 10, dtype=torch.float32).pin_memory()
+    betas_host = torch.empty(B, 10, dtype=torch.float32)
+    if not stub:
+        betas_host = betas_host.pin_memory()
 
     def step():
         with torch.no_grad():
@@ -386,28 +523,28 @@ def run_regressor(args, rank, world, local_rank):
     h0 = net.backbone.register_forward_pre_hook(lambda m, a: ev0[idx['i']].record())
     h1 = net.backbone.register_forward_hook(lambda m, a, o: ev1[idx['i']].record())
 
-    torch.cuda.synchronize()
+    device_sync()
     if world > 1:
         barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         idx['i'] = i
         out, betas = step()
     gatherer.wait()
-    torch.cuda.synchronize()
+    device_sync()
     own_dt = time.perf_counter() - t0
     if world > 1:
         barrier()
-    torch.cuda.synchronize()
+    device_sync()
     dt = time.perf_counter() - t0
     h0.remove(); h1.remove()
     per_rank = None
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        own = torch.tensor([B * args.steps / own_dt], dtype=torch.float64, device='cuda')
+        own = torch.tensor([B * args.steps / own_dt], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(own) for _ in range(world)]
         dist.all_gather(allr, own)
         per_rank = [float(t.item()) for t in allr]
@@ -415,6 +552,28 @@ def run_regressor(args, rank, world, local_rank):
     assert torch.equal(betas_host, out['stage_02']['betas'].cpu())      # the D2H copy landed
     if world > 1:      # the gathered tensor really holds every rank's betas: own shard in place
         assert torch.equal(betas[rank * B:(rank + 1) * B], out['stage_02']['betas'])
+        # ... and every OTHER rank's shard is that rank's own result (checked on rank 0 against
+        # the betas each rank sends separately)
+        mine = out['stage_02']['betas'].contiguous()
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        assert torch.equal(betas, torch.cat(every, dim=0))
+
+    if stub:
+        if rank != 0:
+            return None, None
+        res = {'metric': baseline_metric(), 'value': world * B * args.steps / dt, 'unit': 'images/sec',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+               'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'stub': True,
+               'config': {'workload': 'CPU STUB (--cpu-stub): control-flow test of the N-rank path on '
+                                      'gloo, NOT a measurement', 'global_batch': world * B,
+                          'parallelism': f'dp{world}'},
+               'rccl_ranks': world, 'backend': 'gloo',
+               'per_rank': {'images_per_sec': per_rank,
+                            'allgather': {'issued': gatherer.issued,
+                                          'joined_by_next_step': gatherer.deferred_waits}}}
+        return res, None
 
     backbone_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     flop_img = conv_flop_per_image(net, args.size)
@@ -449,7 +608,7 @@ def run_regressor(args, rank, world, local_rank):
         # measured build of the same workload is quoted as context, labelled with its algorithm
         traffic_other = pmc_traffic(B, args.size, args.dtype, algo, any_algo=True)
     if rank != 0:
-        return None
+        return None, None
     res = {
         'metric': baseline_metric(),
         'value': world * B * args.steps / dt,
@@ -501,12 +660,15 @@ def run_regressor(args, rank, world, local_rank):
         res['per_rank'] = {'images_per_sec': per_rank,
                            'allgather': {'issued': gatherer.issued,
                                          'joined_by_next_step': gatherer.deferred_waits}}
-    if not args.no_cpu_baseline:                     # rank 0 only; oracle outside the timed region
-        base, par = cpu_baseline_and_parity(x_np, out, args.size)
-        res['parity'] = par
-        if world == 1:
-            res['cpu_baseline'] = base
-    return res
+
+    def finish(res):                                 # rank 0 only; after destroy_process_group()
+        if not args.no_cpu_baseline:
+            base, par = cpu_baseline_and_parity(x_np, out, args.size)
+            res['parity'] = par
+            if world == 1:
+                res['cpu_baseline'] = base
+        return res
+    return res, finish
 
 
 def main():
@@ -514,12 +676,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='regressor', choices=['regressor', 'measurements', 'smplx'],
+    ap.add_argument('--workload', default='regressor', choices=['regressor', 'measurements', 'smplx', 'bvh'],
                     help='regressor = BASELINE configs[1] (headline); measurements = configs[3]; '
                          'smplx = the SMPL-X layer alone (configs[0] shape)')
     ap.add_argument('--batch', type=int, default=64, help='images (bodies) per GPU')
     ap.add_argument('--meshes', type=int, default=1000, help='meshes per GPU (measurements)')
     ap.add_argument('--size', type=int, default=224)
+    ap.add_argument('--query-faces', type=int, default=700, help='bvh: query triangles per pair')
+    ap.add_argument('--max-collisions', type=int, default=32, help='bvh: hits kept per query triangle')
     ap.add_argument('--no-cpu-baseline', action='store_true',
                     help='skip the CPU oracle (cpu_baseline and parity fields)')
     ap.add_argument('--single-stream', action='store_true')
@@ -534,11 +698,16 @@ def main():
     ap.add_argument('--tile-flags', default='',
                     help='A/B knob bits OR-ed into every conv\'s tile id (shapy_amd/_lib.py), e.g. '
                          '0x200000 = F(4x4) kernel with the 12-chunk loop unrolled')
+    ap.add_argument('--cpu-stub', action='store_true',
+                    help='TEST HARNESS, never a measurement: gloo ranks + a stub CPU forward, to run the '
+                         'N-rank control flow of this file without GPUs (tests/test_host_cpu.py); '
+                         'the line it prints carries "stub": true')
     ap.add_argument('--wino4-min-hw', type=int, default=0,
                     help='--algo winograd4: smallest map side that takes F(4x4,3x3) (default: the '
                          'backbone\'s own, 28)')
     args = ap.parse_args()
 
+    STUB['on'] = bool(args.cpu_stub)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_spawn(args.gpus))
 
@@ -552,27 +721,41 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with '
                          f'--nproc-per-node {args.gpus} (or without a launcher: bench.py spawns '
                          'its own ranks)')
-    torch.cuda.set_device(local_rank)
+    if STUB['on'] and args.workload != 'regressor':
+        raise SystemExit('--cpu-stub only exercises the regressor workload\'s rank plumbing')
+    if not STUB['on']:
+        torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', init_method='env://')
-    if rank == 0 and not osp.exists(osp.join(ROOT, 'shapy_amd', 'csrc', 'libshapy_hip.so')):
+        # explicit timeout: a rank that dies must fail the job in minutes, not hang the node
+        dist.init_process_group('gloo' if STUB['on'] else 'nccl', init_method='env://',
+                                timeout=datetime.timedelta(seconds=600))
+    if (rank == 0 and not STUB['on']
+            and not osp.exists(osp.join(ROOT, 'shapy_amd', 'csrc', 'libshapy_hip.so'))):
         from shapy_amd import build as hip_build      # fresh checkout: the library is git-ignored
         hip_build.build()
     if world > 1:
         barrier()
 
+    finish = None
     if args.workload == 'measurements':
         res = run_measurements(args, rank, world)
     elif args.workload == 'smplx':
         res = run_smplx(args, rank, world)
+    elif args.workload == 'bvh':
+        res = run_bvh(args, rank, world)
     else:
-        res = run_regressor(args, rank, world, local_rank)
-    if rank == 0:
-        print(json.dumps(res), flush=True)
+        res, finish = run_regressor(args, rank, world, local_rank)
     if world > 1:
+        # every collective of the job is behind us: tear the group down BEFORE rank 0 turns to the
+        # CPU oracle, so that ranks 1..N-1 exit instead of waiting in a barrier for ~15 s
         barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if finish is not None:
+            res = finish(res)
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == '__main__':

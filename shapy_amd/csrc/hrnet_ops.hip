@@ -141,7 +141,12 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
         int rc = join_all();
         if (rc) return rc;
         forked[0] = forked[1] = forked[2] = false;
-        fork_recorded = false;
+        // The fork point of the new epoch is HERE, before any of its ops is enqueued on the main
+        // stream.  (Round 2 recorded it lazily at the first side-lane op -- in plan order that
+        // comes after the main lane's own ops of the epoch, so the side lanes waited for those
+        // too: 100-190 us of a nearly idle chip per epoch, profiles/r03c_timeline_multistream.txt.)
+        SHAPY_HIP_TRY(hipEventRecord(L->fork, main));
+        fork_recorded = true;
       }
       if (o.lane > 0 && o.lane <= 3) {
         const int li = o.lane - 1;

@@ -467,3 +467,50 @@ def test_bf16_plan_keeps_the_48_channel_branch_unpadded():
     f32 = net.backbone._build_plan(64, 64)
     assert [(o['Cin'], o['Cout']) for o in convs] == \
         [(o['Cin'], o['Cout']) for o in f32.ops if o['type'] == 0]
+
+
+# ---- bench.py's N-rank control flow without GPUs ---------------------------
+@pytest.mark.parametrize('launcher', ['self_spawn', 'torchrun'])
+def test_bench_two_ranks_end_to_end_on_gloo_with_stub_forward(launcher):
+    """`bench.py --gpus 2` end to end on the gloo backend with a stub CPU forward: self-spawn
+    command line + env:// rendezvous on 127.0.0.1 (and the driver's own torch.distributed.run
+    form), barriers, the deferred all-gather of the betas checked shard by shard, max-over-ranks
+    timing, teardown BEFORE rank 0's host-side work, exactly ONE JSON line from rank 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = osp.dirname(osp.dirname(osp.abspath(__file__)))
+    tail = ['--gpus', '2', '--cpu-stub', '--steps', '3', '--warmup', '2', '--batch', '4', '--size', '32']
+    if launcher == 'self_spawn':
+        cmd = [sys.executable, osp.join(root, 'bench.py')] + tail
+    else:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+               '--master-addr', '127.0.0.1', '--master-port', str(port),
+               osp.join(root, 'bench.py')] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['stub'] is True and d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['steps'] == 3
+    assert d['config']['global_batch'] == 8 and d['scaling'] == 'weak'
+    assert len(d['per_rank']['images_per_sec']) == 2
+    # 2 warm-up + 3 timed gathers; all but the one joined by wait() after the warm-up and the last
+    # one were joined by the NEXT step's call (the overlap bench.py relies on)
+    assert d['per_rank']['allgather'] == {'issued': 5, 'joined_by_next_step': 3}
+    assert abs(d['value'] - 8 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    import subprocess
+    import sys
+    root = osp.dirname(osp.dirname(osp.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0')
+    r = subprocess.run([sys.executable, osp.join(root, 'bench.py'), '--gpus', '2', '--cpu-stub'],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
