@@ -123,6 +123,17 @@ typedef struct ShapyConv {
 
 int shapy_conv2d(const ShapyConv *desc_host, void *stream);
 
+/* Up to four INDEPENDENT F(4x4,3x3) Winograd layers in one persistent launch
+ * (csrc/conv_wino4g.hip): the convolutions at the same depth of the parallel branches of a
+ * HighResolutionModule -- the reference walks them one branch after the other
+ * (regressor/human_shape/models/backbone/hrnet.py:175-179, `for i in range(self.num_branches):
+ * x[i] = self.branches[i](x[i])`).  Every descriptor must be one that shapy_conv2d would run on
+ * the F(4x4) kernel (float32, SHAPY_TILE_WINO4 set, wgt_wino given, Cin % 16 == 0, Cout % 48 == 0,
+ * tensors within 1 GiB); otherwise SHAPY_EINVAL and nothing is launched -- call shapy_conv2d per
+ * layer instead.  No descriptor may read what another one writes.  Results are bit-identical to n
+ * shapy_conv2d calls. */
+int shapy_conv2d_group(const ShapyConv *descs_host, int n, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * HRNet op list.  The host (Python) flattens the module tree into `ops`; buffers are
  * offsets (in floats, per image) into one workspace allocation that is scaled by B.
@@ -136,6 +147,10 @@ typedef struct ShapyOp {
   int32_t barrier_before;      /* 1: all lanes must have finished before this op starts     */
   int32_t Hi, Wi, Cin, in_ld, Ho, Wo, Cout, ksize, stride, pad;
   int32_t out_ld, out_coff, res_ld, res_coff, relu, ups, tile;
+  int32_t group;               /* > 1 on the FIRST of `group` consecutive CONV ops that are independent
+                                  of each other (same lane, same epoch): they are issued as one
+                                  shapy_conv2d_group launch when every one is an F(4x4) layer,
+                                  otherwise one after the other; 0 / 1 elsewhere             */
   int64_t in_off, out_off, res_off;     /* per-image float offsets into the workspace; -1 = none;
                                             in_off == -2: the network input (STEM)           */
   int64_t wgt_off, bias_off;            /* float offsets into the weight blob; -1 = none     */

@@ -38,7 +38,7 @@ class ShapyOp(ctypes.Structure):
                 ('Hi', i32), ('Wi', i32), ('Cin', i32), ('in_ld', i32), ('Ho', i32), ('Wo', i32),
                 ('Cout', i32), ('ksize', i32), ('stride', i32), ('pad', i32),
                 ('out_ld', i32), ('out_coff', i32), ('res_ld', i32), ('res_coff', i32),
-                ('relu', i32), ('ups', i32), ('tile', i32),
+                ('relu', i32), ('ups', i32), ('tile', i32), ('group', i32),
                 ('in_off', i64), ('out_off', i64), ('res_off', i64),
                 ('wgt_off', i64), ('bias_off', i64), ('wino_off', i64)]
 
@@ -77,6 +77,7 @@ SIGNATURES = {
     'shapy_abi_version': (ctypes.c_int, []),
     'shapy_build_arch': (ctypes.c_char_p, []),
     'shapy_conv2d': (ctypes.c_int, [ctypes.POINTER(ShapyConv), vp]),
+    'shapy_conv2d_group': (ctypes.c_int, [ctypes.POINTER(ShapyConv), ctypes.c_int, vp]),
     'shapy_hrnet_run': (ctypes.c_int, [ctypes.POINTER(ShapyOp), ctypes.c_int, vp, vp, vp, i64, vp,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, vp]),

@@ -23,11 +23,22 @@
 //     of traversal and atomic order (identical to the scan path in measure.hip and to the CPU
 //     oracle as long as no query exceeds max_collisions).
 // Compiled with -ffp-contract=off like measure.hip (bit-identical narrow-phase decisions).
+#include <mutex>
+
 #include "tri_tri.h"
 
 namespace shapy {
 
+#ifdef SHAPY_BVH_TIMING
+__device__ unsigned long long g_bvh_times[16];
+#define BVH_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bvh_times[i] = wall_clock64(); } while (0)
+#else
+#define BVH_STAMP(i) do {} while (0)
+#endif
+
 constexpr int BUILD_THREADS = 1024;
+constexpr int BVH_LDS_KEYS = 16384;                       // 64-bit sort keys held in LDS at a time
+constexpr size_t BVH_LDS_BYTES = (size_t)BVH_LDS_KEYS * 8;   // 128 KB of dynamic LDS (opt-in)
 constexpr int STACK_DEPTH = 64;     // reference STACK_SIZE (:45-47)
 constexpr int QUEUE_CAP = 512;      // candidate pairs buffered per wave
 
@@ -102,6 +113,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void bvh_build_kernel(const float *_
   const float *tb = target + (size_t)b * F * 9;
   BvhMesh m = mesh_ptrs(ws, L, b);
 
+  BVH_STAMP(0);
   // ---- 1. scene bounds = union of the triangle boxes (:140-149, :863-864) ----
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int f = tid; f < F; f += BUILD_THREADS) {
@@ -131,6 +143,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void bvh_build_kernel(const float *_
   }
   __syncthreads();
 
+  BVH_STAMP(1);
   // ---- 2. 30-bit Morton code of the centroid (:613-668), 64-bit unique keys ----
   for (int f = tid; f < L.Fpad; f += BUILD_THREADS) {
     unsigned long long key = ~0ull;
@@ -151,9 +164,36 @@ __global__ __launch_bounds__(BUILD_THREADS) void bvh_build_kernel(const float *_
   }
   __syncthreads();
 
+  BVH_STAMP(2);
   // ---- 3. bitonic sort of the keys (replaces thrust::sort_by_key :911-912) ----
-  for (int k = 2; k <= L.Fpad; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
+  // Blocks of NB keys are sorted / merged inside LDS (128 KB = 16,384 64-bit keys: SMPL-X's 32,768
+  // padded keys are two blocks); only the stages whose partner distance reaches NB go through
+  // global memory (one stage for two blocks).  Round 2 ran all 120 stages through L2 with 16
+  // dependent load-compare-store rounds per thread and stage: ~14 us per mesh after the fence fix.
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  unsigned long long *lk = reinterpret_cast<unsigned long long *>(dyn);
+  const int NB = L.Fpad < BVH_LDS_KEYS ? L.Fpad : BVH_LDS_KEYS;
+  auto lds_stages = [&](int base, int k, int jtop) {      // stages j = jtop .. 1 of merge size k
+    for (int j = jtop; j > 0; j >>= 1) {
+      const int lj = 31 - __clz(j);                        // (j is a power of two: no divisions)
+      for (int q = tid; q < NB / 2; q += BUILD_THREADS) {
+        const int i = ((q >> lj) << (lj + 1)) | (q & (j - 1)), l = i + j;
+        const unsigned long long a = lk[i], c = lk[l];
+        if ((a > c) == (((base + i) & k) == 0)) { lk[i] = c; lk[l] = a; }
+      }
+      __syncthreads();
+    }
+  };
+  for (int base = 0; base < L.Fpad; base += NB) {          // every block: all merge sizes up to NB
+    for (int i = tid; i < NB; i += BUILD_THREADS) lk[i] = m.keys[base + i];
+    __syncthreads();
+    for (int k = 2; k <= NB; k <<= 1) lds_stages(base, k, k >> 1);
+    for (int i = tid; i < NB; i += BUILD_THREADS) m.keys[base + i] = lk[i];
+    __syncthreads();
+  }
+  BVH_STAMP(3);
+  for (int k = 2 * NB; k <= L.Fpad; k <<= 1) {
+    for (int j = k >> 1; j >= NB; j >>= 1) {               // partners in different blocks: global
       for (int i = tid; i < L.Fpad; i += BUILD_THREADS) {
         const int l = i ^ j;
         if (l > i) {
@@ -163,21 +203,49 @@ __global__ __launch_bounds__(BUILD_THREADS) void bvh_build_kernel(const float *_
       }
       __syncthreads();
     }
+    for (int base = 0; base < L.Fpad; base += NB) {
+      for (int i = tid; i < NB; i += BUILD_THREADS) lk[i] = m.keys[base + i];
+      __syncthreads();
+      lds_stages(base, k, NB >> 1);
+      for (int i = tid; i < NB; i += BUILD_THREADS) m.keys[base + i] = lk[i];
+      __syncthreads();
+    }
+  }
 
+  BVH_STAMP(4);
   // ---- 4. Karras radix tree over the sorted keys (:696-765) ----
+  // The ~30 key comparisons per internal node read the sorted keys from LDS when they fit as
+  // (30-bit Morton code, 16-bit face) = 6 bytes per key (SMPL-X: 125 KB); otherwise from L2.
+  const bool lds_keys = F <= 65535 && (size_t)((F + 3) & ~3) * 4 + (size_t)F * 2 <= BVH_LDS_BYTES;
+  unsigned *lmort = reinterpret_cast<unsigned *>(dyn);
+  unsigned short *lface = reinterpret_cast<unsigned short *>(dyn + (size_t)((F + 3) & ~3) * 4);
+  if (lds_keys) {
+    for (int i = tid; i < F; i += BUILD_THREADS) {
+      const unsigned long long k = m.keys[i];
+      lmort[i] = (unsigned)(k >> 32);
+      lface[i] = (unsigned short)(k & 0xffffu);
+    }
+    __syncthreads();
+  }
+  auto dlt = [&](int i, int j) -> int {
+    if (j < 0 || j >= F) return -1;
+    if (!lds_keys) return __clzll(m.keys[i] ^ m.keys[j]);
+    const unsigned x = lmort[i] ^ lmort[j];
+    return x ? __clz(x) : 32 + __clz((unsigned)(lface[i] ^ lface[j]));
+  };
   for (int i = tid; i < F - 1; i += BUILD_THREADS) {
-    const int d = (delta(m.keys, F, i, i + 1) - delta(m.keys, F, i, i - 1)) >= 0 ? 1 : -1;
-    const int dmin = delta(m.keys, F, i, i - d);
+    const int d = (dlt(i, i + 1) - dlt(i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = dlt(i, i - d);
     int lmax = 2;
-    while (delta(m.keys, F, i, i + lmax * d) > dmin) lmax <<= 1;
+    while (dlt(i, i + lmax * d) > dmin) lmax <<= 1;
     int l = 0;
     for (int t = lmax >> 1; t >= 1; t >>= 1)
-      if (delta(m.keys, F, i, i + (l + t) * d) > dmin) l += t;
+      if (dlt(i, i + (l + t) * d) > dmin) l += t;
     const int j = i + l * d;
-    const int dnode = delta(m.keys, F, i, j);
+    const int dnode = dlt(i, j);
     int s = 0;
     for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
-      if (delta(m.keys, F, i, i + (s + t) * d) > dnode) s += t;
+      if (dlt(i, i + (s + t) * d) > dnode) s += t;
       if (t <= 1) break;
     }
     const int gamma = i + s * d + min(d, 0);
@@ -188,11 +256,11 @@ __global__ __launch_bounds__(BUILD_THREADS) void bvh_build_kernel(const float *_
     else { rc = gamma + 1; m.parent_i[gamma + 1] = i; }
     m.left[i] = lc;
     m.right[i] = rc;
-    m.flag[i] = 0;
   }
   if (tid == 0 && F > 1) m.parent_i[0] = -1;
   __syncthreads();
 
+  BVH_STAMP(5);
   // ---- 5. leaf boxes in sorted order + bottom-up refit (:767-821) ----
   for (int k = tid; k < F; k += BUILD_THREADS) {
     const int f = (int)(m.keys[k] & 0xffffffffu);
@@ -207,23 +275,77 @@ __global__ __launch_bounds__(BUILD_THREADS) void bvh_build_kernel(const float *_
     bl[0] = lo[0]; bl[1] = lo[1]; bl[2] = lo[2]; bl[3] = hi[0]; bl[4] = hi[1]; bl[5] = hi[2];
   }
   __syncthreads();
+  BVH_STAMP(6);
   if (F < 2) return;
-  for (int k = tid; k < F; k += BUILD_THREADS) {
-    int node = m.parent_l[k];
-    while (true) {
-      __threadfence();                                  // publish this subtree's boxes
-      if (atomicAdd(&m.flag[node], 1) == 0) break;      // first child to arrive leaves
-      __threadfence();                                  // second: see the sibling's box
-      const int lc = m.left[node], rc = m.right[node];
-      const volatile float *a = lc < 0 ? m.box_l + (size_t)(~lc) * 6 : m.box_i + (size_t)lc * 6;
-      const volatile float *c = rc < 0 ? m.box_l + (size_t)(~rc) * 6 : m.box_i + (size_t)rc * 6;
-      float *o = m.box_i + (size_t)node * 6;
-      o[0] = fminf(a[0], c[0]); o[1] = fminf(a[1], c[1]); o[2] = fminf(a[2], c[2]);
-      o[3] = fmaxf(a[3], c[3]); o[4] = fmaxf(a[4], c[4]); o[5] = fmaxf(a[5], c[5]);
-      if (node == 0) break;
-      node = m.parent_i[node];
+  // Refit in WAVEFRONTS instead of one climbing thread per leaf (the reference's scheme, :767-821,
+  // which round 2 kept: a thread climbs until it is the first to arrive at a node -- with 1,024
+  // threads for 20,908 leaves that is 21 sequential climbs of up to tree-height dependent L2 round
+  // trips each, 0.98 of the build's 1.62 ms per mesh).  Arrival counters (one byte per internal
+  // node) and two ready lists live in LDS; round r computes the boxes of all nodes whose two
+  // children are done -- every thread takes nodes of the list, nobody waits -- and appends the
+  // parents that became ready.  The tree and therefore every box is the same as before.
+  const bool lds_refit = (size_t)((F + 2) / 4 * 4) + (size_t)(F / 2 + 1) * 8 + 16 <= BVH_LDS_BYTES;
+  if (lds_refit) {
+    unsigned *cnt = reinterpret_cast<unsigned *>(dyn);                        // 4 counters per word
+    const int cnt_words = (F + 2) / 4;
+    int *list[2] = {reinterpret_cast<int *>(dyn) + cnt_words, reinterpret_cast<int *>(dyn) + cnt_words + F / 2 + 1};
+    __shared__ int nlist[2];
+    for (int i = tid; i < cnt_words; i += BUILD_THREADS) cnt[i] = 0;
+    if (tid < 2) nlist[tid] = 0;
+    __syncthreads();
+    auto arrive = [&](int node, int which) {        // a child of `node` is done; second arrival: ready
+      const unsigned sh = 8u * (node & 3);
+      const unsigned old = atomicAdd(&cnt[node >> 2], 1u << sh);
+      if (((old >> sh) & 0xffu) == 1u) list[which][atomicAdd(&nlist[which], 1)] = node;
+    };
+    for (int k = tid; k < F; k += BUILD_THREADS) arrive(m.parent_l[k], 0);
+    __syncthreads();
+    for (int cur = 0;; cur ^= 1) {
+      const int n = nlist[cur];
+      if (n == 0) break;
+      __syncthreads();                               // everybody has read n
+      if (tid == 0) nlist[cur ^ 1] = 0;
+      __syncthreads();
+      for (int q = tid; q < n; q += BUILD_THREADS) {
+        const int node = list[cur][q];
+        const int lc = m.left[node], rc = m.right[node];
+        const float *a = lc < 0 ? m.box_l + (size_t)(~lc) * 6 : m.box_i + (size_t)lc * 6;
+        const float *c = rc < 0 ? m.box_l + (size_t)(~rc) * 6 : m.box_i + (size_t)rc * 6;
+        float *o = m.box_i + (size_t)node * 6;
+        o[0] = fminf(a[0], c[0]); o[1] = fminf(a[1], c[1]); o[2] = fminf(a[2], c[2]);
+        o[3] = fmaxf(a[3], c[3]); o[4] = fmaxf(a[4], c[4]); o[5] = fmaxf(a[5], c[5]);
+        if (node != 0) arrive(m.parent_i[node], cur ^ 1);
+      }
+      __syncthreads();                               // (workgroup scope: the boxes of this round are
+    }                                                //  visible to the waves of this CU in the next)
+  } else {
+    for (int i = tid; i < F - 1; i += BUILD_THREADS) m.flag[i] = 0;
+    __syncthreads();
+    for (int k = tid; k < F; k += BUILD_THREADS) {
+      int node = m.parent_l[k];
+      while (true) {
+        // both children of a node are handled by threads of THIS workgroup, i.e. by waves of one
+        // CU that share its L1: workgroup-scope release / acquire is enough.  (Round 2 used
+        // __threadfence() here: on a multi-XCD part an agent-scope fence writes back and
+        // invalidates the XCD's whole L2 -- two of them per node and wave made the build 187 us
+        // PER MESH, 99 % of the LBVH path; profiles/r03n_kernel_stats_bvh_before_fence_fix.csv.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // publish this subtree's boxes
+        if (__hip_atomic_fetch_add(&m.flag[node], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+          break;                                                   // first child to arrive leaves
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // second: see the sibling's box
+        const int lc = m.left[node], rc = m.right[node];
+        const volatile float *a = lc < 0 ? m.box_l + (size_t)(~lc) * 6 : m.box_i + (size_t)lc * 6;
+        const volatile float *c = rc < 0 ? m.box_l + (size_t)(~rc) * 6 : m.box_i + (size_t)rc * 6;
+        float *o = m.box_i + (size_t)node * 6;
+        o[0] = fminf(a[0], c[0]); o[1] = fminf(a[1], c[1]); o[2] = fminf(a[2], c[2]);
+        o[3] = fmaxf(a[3], c[3]); o[4] = fmaxf(a[4], c[4]); o[5] = fmaxf(a[5], c[5]);
+        if (node == 0) break;
+        node = m.parent_i[node];
+      }
     }
   }
+  __syncthreads();
+  BVH_STAMP(7);
 }
 
 __device__ __forceinline__ bool box_overlap(const float *q, const float *n) {
@@ -362,7 +484,20 @@ int mesh_to_mesh_bvh(const float *query, const float *target, int B, int Q, int 
   if (ws_bytes < L.total) return SHAPY_EWORKSPACE;
   char *w = (char *)ws;
   SHAPY_HIP_TRY(hipMemsetAsync(w + L.hits_cnt, 0, (size_t)B * Q * 4, s));
-  hipLaunchKernelGGL(bvh_build_kernel, dim3(B), dim3(BUILD_THREADS), 0, s, target, F, L, w);
+  {
+    // 128 KB of dynamic LDS: opted into per device (the attribute lives in the device's function)
+    static std::mutex mu;
+    static unsigned long long done = 0;
+    int dev = 0;
+    SHAPY_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 64 || !(done >> dev & 1ull)) {
+      SHAPY_HIP_TRY(hipFuncSetAttribute((const void *)bvh_build_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)BVH_LDS_BYTES));
+      if (dev >= 0 && dev < 64) done |= 1ull << dev;
+    }
+  }
+  hipLaunchKernelGGL(bvh_build_kernel, dim3(B), dim3(BUILD_THREADS), BVH_LDS_BYTES, s, target, F, L, w);
   SHAPY_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(bvh_traverse_kernel, dim3((Q + 63) / 64, B), dim3(64), 0, s, query, target, Q,
                      F, MC, L, w, faces_out, bcs_out, overflow);
@@ -374,3 +509,9 @@ int mesh_to_mesh_bvh(const float *query, const float *target, int B, int Q, int 
 }
 
 }  // namespace shapy
+
+#ifdef SHAPY_BVH_TIMING
+extern "C" int shapy_debug_bvh_times(unsigned long long *out_host) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(shapy::g_bvh_times), sizeof(unsigned long long) * 16);
+}
+#endif

@@ -7,12 +7,17 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
               int dtype, hipStream_t main);
 }
 
-extern "C" int shapy_abi_version(void) { return 4; }
+extern "C" int shapy_abi_version(void) { return 5; }
 extern "C" const char *shapy_build_arch(void) { return "gfx950"; }
 
 extern "C" int shapy_conv2d(const ShapyConv *d, void *stream) {
   if (!d) return SHAPY_EINVAL;
   return shapy::conv2d(*d, (hipStream_t)stream);
+}
+
+extern "C" int shapy_conv2d_group(const ShapyConv *descs, int n, void *stream) {
+  if (!descs) return SHAPY_EINVAL;
+  return shapy::conv2d_group(descs, n, (hipStream_t)stream);
 }
 
 extern "C" int shapy_hrnet_run(const ShapyOp *ops, int n_ops, const void *weights,

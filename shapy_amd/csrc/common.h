@@ -26,6 +26,7 @@ enum {
 };
 
 int conv2d(const ShapyConv &d, hipStream_t s);
+int conv2d_group(const ShapyConv *ds, int n, hipStream_t s);
 int conv_tile_auto(int M, int Cout);
 int conv_tile_auto_x6(int M, int Cout, int K);
 

@@ -56,6 +56,8 @@ int conv2d_wino(ConvK k, int tm, hipStream_t s);
 // Winograd F(4x4,3x3) path (conv_wino4.hip): k.wgt2 holds [36][Cin/16][Cout][16] filters
 int conv2d_wino4(ConvK k, hipStream_t s);
 bool conv_wino4_fits(const ConvK &k);
+// persistent grouped F(4x4) launch (conv_wino4g.hip): up to 4 layers
+int conv2d_wino4_group(const ConvK *ks, int n, hipStream_t s);
 
 // float32 storage, bf16x6 split arithmetic on the bf16 matrix cores (conv_x6.hip)
 int conv2d_x6(const ConvK &k, int tile, hipStream_t s);

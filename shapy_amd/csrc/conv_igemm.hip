@@ -318,7 +318,10 @@ static int dispatch(const ConvK &k, int tile, int kq, hipStream_t s) {
   }
 }
 
-int conv2d(const ShapyConv &d, hipStream_t s) {
+// Validates a descriptor and fills the kernel argument block up to (not including) the choice of
+// algorithm / tile.  *empty = 1: nothing to compute (M or Cout is 0).
+int conv_prepare(const ShapyConv &d, ConvK &k, int *empty) {
+  *empty = 0;
   const bool bf16 = d.dtype == SHAPY_DTYPE_BF16, x6 = d.dtype == SHAPY_DTYPE_F32X6;
   if (d.dtype != SHAPY_DTYPE_F32 && !bf16 && !x6) return SHAPY_EINVAL;
   const int esz = bf16 ? 2 : 4, eps = 16 / esz;          // element size, elements per slot
@@ -329,7 +332,6 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
       d.stride < 1 || d.ups < 1 || (flat && (d.Cin < 32 || d.ups != 1)))
     return SHAPY_EINVAL;
   if (((uintptr_t)d.in | (uintptr_t)d.wgt) & 15) return SHAPY_EINVAL;
-  ConvK k;
   k.in = d.in; k.wgt = d.wgt; k.bias = d.bias; k.res = d.res; k.out = d.out;
   k.M = d.B * d.Ho * d.Wo;
   k.Hi = d.Hi; k.Wi = d.Wi; k.Cin = d.Cin; k.in_ld = d.in_ld; k.Ho = d.Ho; k.Wo = d.Wo;
@@ -347,7 +349,7 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
       x6 ? 6ull * d.Cout * k.Kp : (unsigned long long)esz * d.Cout * d.ksize * d.ksize * d.Cin;
   if (in_bytes >= 0x7fffffffull || wgt_bytes >= 0x7fffffffull) return SHAPY_EINVAL;   // 32-bit offsets
   k.in_bytes = (unsigned)in_bytes; k.wgt_bytes = (unsigned)wgt_bytes;
-  if (k.M <= 0 || k.Cout <= 0) return SHAPY_OK;
+  if (k.M <= 0 || k.Cout <= 0) *empty = 1;
   // Winograd F(2x2,3x3) when the caller supplies the transformed filters (the host's policy,
   // HighResolutionNet.conv_algo); tile flag 0x2000 forces the direct kernel, 0x4000 / 0x8000
   // one / two tile groups per Winograd workgroup (A/B benches)
@@ -358,6 +360,17 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   k.dbg = 0;
   k.w4_unroll12 = 0;
   k.flat = flat ? 1 : 0;
+  return SHAPY_OK;
+}
+
+int conv2d(const ShapyConv &d, hipStream_t s) {
+  ConvK k;
+  int empty = 0;
+  const int rc0 = conv_prepare(d, k, &empty);
+  if (rc0 != SHAPY_OK || empty) return rc0;
+  const bool bf16 = d.dtype == SHAPY_DTYPE_BF16, x6 = d.dtype == SHAPY_DTYPE_F32X6;
+  const int eps = bf16 ? 8 : 4;
+  const bool flat = k.flat != 0;
   // three chunks of global loads in flight: bf16 always (its chunks are 50-100 ns of MFMAs);
   // float32 on request (tile flag 0x40000, A/B benches)
   k.pd3 = (bf16 || (d.tile & 0x40000)) && !(d.tile & 0x80000) ? 1 : 0;
@@ -405,6 +418,28 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   if (flat) { tile = SHAPY_TILE_64x48; kq = 4; }
   if (x6) return conv2d_x6(k, tile, s);
   return bf16 ? dispatch<BF16>(k, tile, kq, s) : dispatch<F32>(k, tile, kq, s);
+}
+
+// Several F(4x4,3x3) layers in ONE persistent launch (conv_wino4g.hip).  Every descriptor must be
+// a layer shapy_conv2d would run on the F(4x4) kernel (SHAPY_TILE_WINO4 set, float32, wgt_wino
+// given, within its 1 GiB addressing); anything else is SHAPY_EINVAL -- the caller falls back to
+// one shapy_conv2d per layer.
+int conv2d_group(const ShapyConv *ds, int n, hipStream_t s) {
+  if (!ds || n < 1 || n > 4) return SHAPY_EINVAL;
+  ConvK ks[4];
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const ShapyConv &d = ds[i];
+    if (d.dtype != SHAPY_DTYPE_F32 || !(d.tile & 0x100000) || !d.wgt_wino) return SHAPY_EINVAL;
+    int empty = 0;
+    const int rc = conv_prepare(d, ks[m], &empty);
+    if (rc != SHAPY_OK) return rc;
+    if (empty) continue;
+    if (!conv_wino4_fits(ks[m]) || !conv_wino_eligible(ks[m])) return SHAPY_EINVAL;
+    ++m;
+  }
+  if (m == 0) return SHAPY_OK;
+  return conv2d_wino4_group(ks, m, s);
 }
 
 }  // namespace shapy

@@ -38,6 +38,16 @@
 
 namespace shapy {
 
+// Ablation switches of tuning builds (-DSHAPY_WINO_TIMING, ConvK.dbg from SHAPY_WINO_DBG; results are
+// WRONG on purpose): 1 no output stores, 2 no residual loads, 4 a quarter of the MFMAs, 8 no filter
+// refills after the first ring, 16 patch loaded once (first chunk's registers reused), 32 no input
+// transform / LDS stores in the staging wave
+#ifdef SHAPY_WINO_TIMING
+#define W4_DBG(bit) (p.dbg & (bit))
+#else
+#define W4_DBG(bit) false
+#endif
+
 #ifndef WINO4_RING
 #define WINO4_RING 12         // B-fragment positions in flight per multiplying wave (divides 36)
 #endif
@@ -147,6 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) gload_col(j, 0);
     for (int cc = 0; cc < CC; ++cc) {
+      if (W4_DBG(32)) { wino4_lds_barrier(); continue; }
       // chunk cc -> V buffer cc & 1.  That buffer was last read by the multiply of chunk
       // cc - 2, which every wave left through the barrier this wave passed at the end of the
       // previous iteration.
@@ -162,15 +173,30 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
       char *Vb = lds + (cc & 1) * LDS_V + st_off;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {                                // V = B^T T  (along y)
-        const f32x4 colv[6] = {raw[0][j], raw[1][j], raw[2][j], raw[3][j], raw[4][j], raw[5][j]};
-        f32x4 v[6];
-        wino4_bt(colv, v);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4 *>(Vb + (6 * i + j) * PSTR) = v[i];
+        // (each output goes to LDS as soon as it exists: with all six held at once the staging
+        // loop needed 10 registers more than the 256 a wave has, and ANY scratch costs ~17 us
+        // per LAUNCH on this GPU -- tools/launch_floor.hip: 3.1 us for an empty kernel, 19-22 us
+        // for one that touches its private segment)
+        {
+          auto st = [&](int i, const f32x4 v) { *reinterpret_cast<f32x4 *>(Vb + (6 * i + j) * PSTR) = v; };
+          const f32x4 d0 = raw[0][j], d1 = raw[1][j], d2 = raw[2][j], d3 = raw[3][j], d4 = raw[4][j],
+                      d5 = raw[5][j];
+          st(0, 4.f * d0 - 5.f * d2 + d4);
+          __builtin_amdgcn_sched_barrier(0);
+          st(5, 4.f * d1 - 5.f * d3 + d5);
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x4 a = d4 - 4.f * d2, b = d3 - 4.f * d1;
+          st(1, a + b);
+          st(2, a - b);
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x4 c = d4 - d2, e = d3 - d1;
+          st(3, c + 2.f * e);
+          st(4, c - 2.f * e);
+        }
         // the column's registers are free again: request the same column of the NEXT chunk, which
         // then has a whole multiply phase to arrive
         __builtin_amdgcn_sched_barrier(0);
-        if (more) gload_col(j, (cc + 1) * 16);
+        if (more && !W4_DBG(16)) gload_col(j, (cc + 1) * 16);
         __builtin_amdgcn_sched_barrier(0);
       }
       wino4_lds_barrier();                   // chunk cc is staged (barrier #cc of CC + 1)
@@ -221,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
       // dependent latency vs a 32-cycle issue interval)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
+        if (W4_DBG(4) && kk > 0) break;
         acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(
             __uint_as_float(af[cur][0][kk]), __uint_as_float(bring[pp % R][kk]), acc[pp], 0, 0, 0);
         acc[pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
@@ -233,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int q = pp + e + R;
+        if (W4_DBG(8)) continue;
         if (q < 36) bload((pp + e) % R, q, cc, true);
         else bload((pp + e) % R, q - 36, cc + 1, more);
       }
@@ -281,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) {
-        const bool ok = (a < nrow[r]) & (bb < ncol[r]);
+        const bool ok = (a < nrow[r]) & (bb < ncol[r]) & !W4_DBG(2);
         rv[4 * a + bb] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
             rs_res, ok ? rbase[r] : BAD, (a * W + bb) * p.res_ld * 4, 0));
       }
@@ -304,8 +332,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
       wino4_at(colv, y);                                          // A^T (M A)   (along y)
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const bool ok = (a < nrow[r]) & (bb < ncol[r]);
+        bool ok = (a < nrow[r]) & (bb < ncol[r]);
         float v = (y[a] + bias) + resv[r & 1][4 * a + bb];
+        if (W4_DBG(1)) ok &= v == 12345.678f;
         if (p.relu) v = fmaxf(v, 0.f);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, ok ? obase[r] : BAD,
                                               (a * W + bb) * p.out_ld * 4, 0);
@@ -330,6 +359,9 @@ int conv2d_wino4(ConvK k, hipStream_t s) {
   k.wgt2_bytes = (unsigned)(144ull * k.Cin * k.Cout);          // 36 positions x f32
   k.nbx = k.Cout / 48;
   k.nby = (k.wino_tiles + 15) / 16;
+#ifdef SHAPY_WINO_TIMING
+  k.dbg = getenv("SHAPY_WINO_DBG") ? atoi(getenv("SHAPY_WINO_DBG")) : 0;
+#endif
   // transformed filters larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
   if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt2_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
   const dim3 grid(k.nbx * k.nby), blk(256);

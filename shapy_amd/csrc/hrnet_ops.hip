@@ -165,21 +165,45 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
     auto buf = [&](int64_t off) -> char * {
       return off < 0 ? nullptr : (char *)ws + off * (int64_t)B * esz;
     };
-    if (o.type == SHAPY_OP_CONV) {
-      ShapyConv d;
-      d.in = buf(o.in_off);
-      d.wgt = (const char *)weights + o.wgt_off * esz;
-      d.bias = o.bias_off >= 0 ? wf32 + o.bias_off : nullptr;
+    auto make_desc = [&](const ShapyOp &q, ShapyConv &d) {
+      d.in = buf(q.in_off);
+      d.wgt = (const char *)weights + q.wgt_off * esz;
+      d.bias = q.bias_off >= 0 ? wf32 + q.bias_off : nullptr;
       d.dtype = dtype;
-      d.res = buf(o.res_off);
-      d.out = buf(o.out_off);
-      d.B = B; d.Hi = o.Hi; d.Wi = o.Wi; d.Cin = o.Cin; d.in_ld = o.in_ld;
-      d.Ho = o.Ho; d.Wo = o.Wo; d.Cout = o.Cout; d.ksize = o.ksize; d.stride = o.stride;
-      d.pad = o.pad; d.out_ld = o.out_ld; d.out_coff = o.out_coff; d.res_ld = o.res_ld;
-      d.res_coff = o.res_coff; d.relu = o.relu; d.ups = o.ups; d.tile = o.tile;
+      d.res = buf(q.res_off);
+      d.out = buf(q.out_off);
+      d.B = B; d.Hi = q.Hi; d.Wi = q.Wi; d.Cin = q.Cin; d.in_ld = q.in_ld;
+      d.Ho = q.Ho; d.Wo = q.Wo; d.Cout = q.Cout; d.ksize = q.ksize; d.stride = q.stride;
+      d.pad = q.pad; d.out_ld = q.out_ld; d.out_coff = q.out_coff; d.res_ld = q.res_ld;
+      d.res_coff = q.res_coff; d.relu = q.relu; d.ups = q.ups; d.tile = q.tile;
       d.reserved0 = 0;
-      d.wgt_wino = (dtype == SHAPY_DTYPE_F32 && o.wino_off >= 0) ? wf32 + o.wino_off : nullptr;
-      int rc = conv2d(d, s);
+      d.wgt_wino = (dtype == SHAPY_DTYPE_F32 && q.wino_off >= 0) ? wf32 + q.wino_off : nullptr;
+    };
+    if (o.type == SHAPY_OP_CONV) {
+      int rc = SHAPY_OK;
+      if (o.group > 1) {
+        // `group` independent layers of one depth level (same lane): ONE persistent F(4x4) launch
+        // when all of them qualify, else one launch each on this stream
+        const int n = o.group;
+        if (n > 4 || idx + n > n_ops) return SHAPY_EINVAL;
+        ShapyConv ds[4];
+        for (int k = 0; k < n; ++k) {
+          if (ops[idx + k].type != SHAPY_OP_CONV || ops[idx + k].lane != o.lane ||
+              (k > 0 && ops[idx + k].barrier_before))
+            return SHAPY_EINVAL;
+          make_desc(ops[idx + k], ds[k]);
+        }
+        rc = conv2d_group(ds, n, s);
+        if (rc == SHAPY_EINVAL) {
+          rc = SHAPY_OK;
+          for (int k = 0; k < n && rc == SHAPY_OK; ++k) rc = conv2d(ds[k], s);
+        }
+        idx += n - 1;
+      } else {
+        ShapyConv d;
+        make_desc(o, d);
+        rc = conv2d(d, s);
+      }
       if (rc) {
         if (multi_stream) join_all();        // leave no forked lane unjoined behind an error
         return rc;

@@ -34,7 +34,7 @@ from ...utils import winograd
 BN_MOMENTUM = 0.1
 #: product defaults of HighResolutionNet.conv_algo / .wino4_min_hw (see there)
 DEFAULT_CONV_ALGO = 'winograd4'
-DEFAULT_WINO4_MIN_HW = 14
+DEFAULT_WINO4_MIN_HW = 7
 
 
 # ------------------------------------------------------------------------------------------
@@ -183,6 +183,8 @@ class _Plan:
         self.wbytes = 0
         self.epoch = 0
         self._pending_barrier = False
+        self._group_left = 0   # ops still to come in the current launch group
+        self._group_t = 0      # ... and the group's time index (= op index of its first op)
 
     def padc(self, c):
         """bf16 rows are addressed in 16-byte slots of 8 channels (every HRNet width already is a
@@ -233,10 +235,21 @@ class _Plan:
             self._pending_barrier = False
         else:
             kw.setdefault('barrier_before', 0)
+        # the ops of a launch group run CONCURRENTLY (one persistent kernel): for the liveness
+        # packing they all happen at the time of the group's first op
+        kw.setdefault('group', 0)
+        if self._group_left > 0:
+            assert kw['group'] == 0 and not kw['barrier_before']
+            self._group_left -= 1
+            t = self._group_t
+        else:
+            t = len(self.ops)
+            if kw['group'] > 1:
+                self._group_left, self._group_t = kw['group'] - 1, t
         for key in ('inb', 'outb', 'resb'):
             b = kw.get(key)
             if b is not None:
-                b.uses.append((self.epoch, kw['lane'], len(self.ops)))
+                b.uses.append((self.epoch, kw['lane'], t))
         self.ops.append(kw)
 
     def allocate(self):
@@ -366,6 +379,10 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.conv_algo = os.environ.get('SHAPY_CONV_ALGO', DEFAULT_CONV_ALGO)
         self.wino_min_hw = 14
         self.wino4_min_hw = int(os.environ.get('SHAPY_WINO4_MIN_HW', DEFAULT_WINO4_MIN_HW))
+        #: conv_algo='winograd4': the convs at the same depth of a HighResolutionModule's parallel
+        #: branches as ONE persistent grouped launch (csrc/conv_wino4g.hip) instead of one launch
+        #: per branch on its own stream; bit-identical features either way
+        self.group_branches = os.environ.get('SHAPY_GROUP_BRANCHES', '1') != '0'
         self._engine_ver = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
 
@@ -496,7 +513,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             raise ValueError(f'unknown conv_algo {self.conv_algo!r}')
 
         def conv(conv_m, bn, inb, Hi, Wi, outb=None, res=None, relu=False, ups=1, lane=0,
-                 out_ld=None, out_coff=0, res_ld=None, res_coff=0, name=''):
+                 out_ld=None, out_coff=0, res_ld=None, res_coff=0, name='', group=0):
             ks, st, pad = conv_m.kernel_size[0], conv_m.stride[0], conv_m.padding[0]
             cin, cout = conv_m.in_channels, conv_m.out_channels
             cin_p, cout_p = P.padc(cin), P.padc(cout)
@@ -524,7 +541,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                  relu=int(relu), ups=ups,
                  tile=_lib.TILES[ov.get(name, 'auto')] | self.tile_flags | wino_flag,
                  wgt_off=P.add_conv_weights(w), bias_off=P.add_weights(b), wino_off=wino_off,
-                 name=name)
+                 name=name, group=group)
             return outb, Ho, Wo
 
         # stem (hrnet.py:427-432)
@@ -572,14 +589,44 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             """xs: list of (buf, H, W).  HighResolutionModule.forward (hrnet.py:175-193)."""
             nb = m.num_branches
             ys = []
-            for i in range(nb):
-                x, Hc, Wc = xs[i]
-                for bi, blk in enumerate(m.branches[i]):
-                    t, _, _ = conv(blk.conv1, blk.bn1, x, Hc, Wc, relu=True, lane=i,
-                                   name=f'{name}.branches.{i}.{bi}.conv1')
-                    x, _, _ = conv(blk.conv2, blk.bn2, t, Hc, Wc, res=x, relu=True, lane=i,
-                                   name=f'{name}.branches.{i}.{bi}.conv2')
-                ys.append((x, Hc, Wc))
+            depth = len(m.branches[0])
+            grouped = (self.group_branches and not (bf16 or x6) and 2 <= nb <= 4
+                       and all(len(br) == depth for br in m.branches)
+                       and all(self._use_wino4(3, 1, 1, c.in_channels, c.out_channels, xs[i][1],
+                                               xs[i][2], 1)
+                               for i in range(nb) for blk in m.branches[i]
+                               for c in (blk.conv1, blk.conv2)))
+            if grouped:
+                # level-major: the convs at the same depth of the nb branches are independent ->
+                # ONE persistent F(4x4) launch per level on the main stream (csrc/conv_wino4g.hip)
+                # instead of nb launches on nb streams; the reference walks branch by branch
+                # (hrnet.py:175-179)
+                P.barrier()
+                cur = [xs[i][0] for i in range(nb)]
+                for bi in range(depth):
+                    ts = []
+                    for i in range(nb):
+                        blk = m.branches[i][bi]
+                        t, _, _ = conv(blk.conv1, blk.bn1, cur[i], xs[i][1], xs[i][2], relu=True,
+                                       lane=0, name=f'{name}.branches.{i}.{bi}.conv1',
+                                       group=nb if i == 0 else 0)
+                        ts.append(t)
+                    for i in range(nb):
+                        blk = m.branches[i][bi]
+                        cur[i], _, _ = conv(blk.conv2, blk.bn2, ts[i], xs[i][1], xs[i][2],
+                                            res=cur[i], relu=True, lane=0,
+                                            name=f'{name}.branches.{i}.{bi}.conv2',
+                                            group=nb if i == 0 else 0)
+                ys = [(cur[i], xs[i][1], xs[i][2]) for i in range(nb)]
+            else:
+                for i in range(nb):
+                    x, Hc, Wc = xs[i]
+                    for bi, blk in enumerate(m.branches[i]):
+                        t, _, _ = conv(blk.conv1, blk.bn1, x, Hc, Wc, relu=True, lane=i,
+                                       name=f'{name}.branches.{i}.{bi}.conv1')
+                        x, _, _ = conv(blk.conv2, blk.bn2, t, Hc, Wc, res=x, relu=True, lane=i,
+                                       name=f'{name}.branches.{i}.{bi}.conv2')
+                    ys.append((x, Hc, Wc))
             P.barrier()
             outs = []
             for i in range(len(m.fuse_layers)):
@@ -681,7 +728,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             self._engine = {}
             self._engine_ver = ver
         key = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
-               self.wino4_min_hw, self.tile_flags, tuple(sorted(self.tile_overrides.items())))
+               self.wino4_min_hw, self.group_branches, self.tile_flags, tuple(sorted(self.tile_overrides.items())))
         eng = self._engine.get(key)
         if eng is not None:
             return eng
@@ -693,7 +740,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             a = arr[i]
             for f in ('type', 'lane', 'barrier_before', 'Hi', 'Wi', 'Cin', 'in_ld', 'Ho', 'Wo',
                       'Cout', 'ksize', 'stride', 'pad', 'out_ld', 'out_coff', 'res_ld', 'res_coff',
-                      'relu', 'ups', 'tile', 'wgt_off', 'bias_off', 'wino_off'):
+                      'relu', 'ups', 'tile', 'group', 'wgt_off', 'bias_off', 'wino_off'):
                 setattr(a, f, int(o[f]))
             a.in_off = -2 if o['type'] == _lib.OP_STEM else o['inb'].off
             a.out_off = -1 if o['outb'] is None else o['outb'].off

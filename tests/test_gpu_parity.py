@@ -534,6 +534,68 @@ def test_hrnet_graph_replay_equals_eager(network, multi_stream):
     assert g0.data_ptr() != g0b.data_ptr()               # outputs are copies, not the baked buffer
 
 
+@pytest.mark.parametrize('B,size,multi_stream,graph', [(3, 96, True, False), (2, 224, False, False),
+                                                       (64, 224, True, False), (2, 64, True, True)])
+def test_hrnet_grouped_branch_launches_equal_per_layer_launches(network, B, size, multi_stream, graph):
+    """group_branches (the default): the convs at one depth of a module's parallel branches run as
+    ONE persistent F(4x4) launch (csrc/conv_wino4g.hip, through shapy_hrnet_run's `group` ops)
+    instead of one conv_wino4 launch per branch and stream -- same tasks, same arithmetic:
+    bit-identical features, at the headline batch too, eager and as a captured hipGraph."""
+    from shapy_amd.utils import synthetic as syn
+    bb = network.backbone
+    keep = bb.group_branches, bb.multi_stream, bb.use_graph, bb.conv_algo, bb.wino4_min_hw
+    x = torch.from_numpy(syn.synthetic_images(B, size, 11)).cuda()
+    try:
+        bb.conv_algo, bb.wino4_min_hw = 'winograd4', 7
+        bb.multi_stream, bb.use_graph = multi_stream, graph
+        bb.group_branches = False
+        with torch.no_grad():
+            ref = bb(x)['concat'].clone()
+        bb.group_branches = True
+        with torch.no_grad():
+            got = bb(x)['concat'].clone()
+            again = bb(x)['concat'].clone()
+        torch.cuda.synchronize()
+        plan = [e for k, e in bb._engine.items() if k[7] is True][-1]['plan']
+        # 224 px: every module's branch levels (8 x 2 + 32 x 3 + 24 x 4 layers); smaller inputs: the
+        # modules whose smallest map stays >= wino4_min_hw
+        assert sum(1 for o in plan.ops if o['group'] > 1) == (64 if size == 224 else 8)
+    finally:
+        bb.group_branches, bb.multi_stream, bb.use_graph, bb.conv_algo, bb.wino4_min_hw = keep
+    assert torch.equal(got, ref) and torch.equal(again, ref)
+
+
+def test_conv2d_group_c_abi_matches_single_launches():
+    """shapy_conv2d_group through the C-ABI: groups of 1-4 layers incl. partly filled workgroups,
+    a channel-offset epilogue, Cout = 144 (the generic XCD split), more tasks than workgroup slots;
+    refusals leave the outputs untouched."""
+    _need_gpu()
+    import subprocess
+    import sys
+    root = osp.dirname(osp.dirname(osp.abspath(__file__)))
+    r = subprocess.run([sys.executable, osp.join(root, 'tools', 'wino4g_check.py'), '--canary'],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'CANARY OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    from shapy_amd import _lib
+    lib = _lib.load()
+    # a layer that is not an F(4x4) layer -> SHAPY_EINVAL, nothing launched
+    x = torch.randn(1, 8, 8, 16).cuda()
+    w = torch.randn(48, 3, 3, 16).cuda()
+    out = torch.full((1, 8, 8, 48), 7.0).cuda()
+    d = _lib.ShapyConv()
+    d.dtype = _lib.DTYPE_F32
+    d.in_ = x.data_ptr(); d.wgt = w.data_ptr(); d.out = out.data_ptr()
+    d.B, d.Hi, d.Wi, d.Cin, d.in_ld = 1, 8, 8, 16, 16
+    d.Ho, d.Wo, d.Cout = 8, 8, 48
+    d.ksize, d.stride, d.pad, d.out_ld, d.ups = 3, 1, 1, 48, 1
+    arr = (_lib.ShapyConv * 1)(d)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.shapy_conv2d_group(arr, 1, stream) == -1
+    assert lib.shapy_conv2d_group(arr, 5, stream) == -1
+    torch.cuda.synchronize()
+    assert (out == 7.0).all()
+
+
 @pytest.mark.parametrize('tag,b,s', [('b2_64', 2, 64), ('b1_224', 1, 224)])
 def test_hrnet_bf16_features_vs_f32_golden(network, golden_dir, tag, b, s):
     """BASELINE configs[2]: bf16 weights/activations, f32 accumulate.  It does not meet the 1e-4

@@ -55,7 +55,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.shapy_abi_version() == 4
+    assert lib.shapy_abi_version() == 5
     assert lib.shapy_build_arch() == b'gfx950'
     # struct layouts agree with the C header (sizeof through a tiny C program)
     src = '#include <stdio.h>\n#include "shapy_hip.h"\nint main(){printf("%zu %zu %zu", ' \
@@ -465,8 +465,9 @@ def test_bf16_plan_keeps_the_48_channel_branch_unpadded():
         if o['Cin'] % 32:                      # flat-K kernel: no upsample epilogue, Cin >= 32
             assert o['ups'] == 1 and o['Cin'] >= 32, o
     f32 = net.backbone._build_plan(64, 64)
-    assert [(o['Cin'], o['Cout']) for o in convs] == \
-        [(o['Cin'], o['Cout']) for o in f32.ops if o['type'] == 0]
+    # (same layers; the float32 plan lists the branch convs level by level: grouped launches)
+    assert sorted((o['Cin'], o['Cout']) for o in convs) == \
+        sorted((o['Cin'], o['Cout']) for o in f32.ops if o['type'] == 0)
 
 
 # ---- bench.py's N-rank control flow without GPUs ---------------------------
@@ -514,3 +515,45 @@ def test_bench_refuses_a_world_size_mismatch():
     r = subprocess.run([sys.executable, osp.join(root, 'bench.py'), '--gpus', '2', '--cpu-stub'],
                        capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
+
+
+def test_grouped_branch_levels_plan(hrnet):
+    """conv_algo='winograd4' with group_branches: the branch convs of every HighResolutionModule are
+    listed level by level on lane 0, the first op of a level carries the group size, the ops of a
+    group are independent (nobody reads or writes what another one writes) and never share memory."""
+    keep = hrnet.conv_algo, hrnet.wino4_min_hw, hrnet.group_branches
+    try:
+        hrnet.conv_algo, hrnet.wino4_min_hw, hrnet.group_branches = 'winograd4', 7, True
+        P = hrnet._build_plan(224, 224)
+        P.allocate()
+        ops = P.ops
+        groups = [(i, o['group']) for i, o in enumerate(ops) if o['group'] > 1]
+        assert sorted(collections_counter(g for _, g in groups).items()) == [(2, 8), (3, 32), (4, 24)]
+        for i, n in groups:
+            members = ops[i:i + n]
+            assert all(m['type'] == 0 and m['lane'] == 0 for m in members)
+            assert all(m['group'] == 0 and not m['barrier_before'] for m in members[1:])
+            assert all(m.get('wino_off', -1) >= 0 and m['ksize'] == 3 and m['stride'] == 1 for m in members)
+            for a in range(n):
+                for b in range(n):
+                    if a == b:
+                        continue
+                    wa = members[a]['outb']
+                    for key in ('inb', 'resb', 'outb'):
+                        other = members[b][key]
+                        if other is None:
+                            continue
+                        assert other is not wa
+                        assert wa.off + wa.size <= other.off or other.off + other.size <= wa.off
+        # the same layers as the ungrouped plan, each exactly once
+        hrnet.group_branches = False
+        Q = hrnet._build_plan(224, 224)
+        assert sorted(o['name'] for o in ops if o['type'] == 0) == sorted(o['name'] for o in Q.ops if o['type'] == 0)
+        assert all(o['group'] == 0 for o in Q.ops)
+    finally:
+        hrnet.conv_algo, hrnet.wino4_min_hw, hrnet.group_branches = keep
+
+
+def collections_counter(it):
+    import collections
+    return collections.Counter(it)
