@@ -53,6 +53,7 @@ struct W4Conv {
 struct W4Group {
   W4Conv c[4];
   int n;
+  int dbg;                 // tuning builds only (SHAPY_W4G_DBG)
   // schedule: slot s (= blockIdx.x / 8) of every XCD runs, for g = 0 .. n-1, the tasks
   // [first[g][s], first[g][s] + count[g][s]) of convolution g's per-XCD list (clipped to the
   // list's length on this XCD: lists differ by at most one task between XCDs)
@@ -212,6 +213,7 @@ __device__ __forceinline__ int w4g_task(const W4Group &G, const int task, int &g
   asm volatile("" : "+s"(task_e));
   W4G_STAMP(0, 4);
   Wino4Epi e;
+  e.dbg = G.dbg;
   e.out = c.out; e.res = c.res; e.in = c.in; e.bias = c.bias;
   e.H = c.Hi; e.W = c.Wi; e.tiles = c.tiles; e.out_ld = c.out_ld; e.out_coff = c.out_coff;
   e.res_ld = c.res_ld; e.res_coff = c.res_coff; e.relu = c.relu;
@@ -376,6 +378,10 @@ int conv2d_wino4_group(const ConvK *ks, int n, hipStream_t s) {
   if (n < 1 || n > 4) return SHAPY_EINVAL;
   W4Group G;
   G.n = n;
+  G.dbg = 0;
+#ifdef SHAPY_W4G_TIMING
+  G.dbg = getenv("SHAPY_W4G_DBG") ? atoi(getenv("SHAPY_W4G_DBG")) : 0;
+#endif
   long tasks = 0;
   for (int i = 0; i < n; ++i) {
     const ConvK &k = ks[i];

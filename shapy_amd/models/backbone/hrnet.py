@@ -382,7 +382,19 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: conv_algo='winograd4': the convs at the same depth of a HighResolutionModule's parallel
         #: branches as ONE persistent grouped launch (csrc/conv_wino4g.hip) instead of one launch
         #: per branch on its own stream; bit-identical features either way
-        self.group_branches = os.environ.get('SHAPY_GROUP_BRANCHES', '1') != '0'
+        #: 'auto' (default) = only when the forward runs on ONE stream: on four streams the per-layer
+        #: launches overlap the fuse layers of a module with the first convs of the next and are the
+        #: faster configuration at every batch size measured (B = 64: 4,745 vs 4,662 images/s; one
+        #: stream: 14.1 vs 16.3 ms per step in favour of the groups; profiles/r03m_*)
+        self.group_branches = {'1': True, '0': False}.get(os.environ.get('SHAPY_GROUP_BRANCHES', ''), 'auto')
+        #: Winograd numerics guard: per-layer demotions {op name: 'winograd' (F(2x2)) | 'direct'} found
+        #: by ``calibrate`` for the CURRENT weights; wino_guard = run the calibration on the first
+        #: float32 batch after the weights changed (SHAPY_WINO_GUARD=0 disables)
+        self.layer_algo = {}
+        self.wino_guard = os.environ.get('SHAPY_WINO_GUARD', '1') != '0'
+        self.wino_budget = 2e-5          # rms(winograd - direct) / rms(direct) per layer
+        self.calibration_report = None
+        self._calibrated_ver = None
         self._engine_ver = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
 
@@ -483,6 +495,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         automatically when a parameter / buffer version changes (``_compile``), after
         ``load_state_dict`` and after ``.to()`` / ``.cuda()``."""
         self._engine = {}
+        self._calibrated_ver = None
         self._drop_version_cache()
 
     def _apply(self, fn, *a, **k):
@@ -496,6 +509,10 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         st['_engine'] = {}
         st['_ver_tensors'] = None
         return st
+
+    def _group_on(self):
+        g = self.group_branches
+        return (not self.multi_stream) if g == 'auto' else bool(g)
 
     def _use_wino(self, ks, st, pad, cin, cout, Hi, Wi, ups):
         if self.conv_algo == 'direct' or not winograd.eligible(ks, st, pad, cin, cout, ups):
@@ -529,7 +546,12 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             if outb is None:
                 outb = P.buf(Ho * ups, Wo * ups, cout_p)
             wino_off, wino_flag = -1, 0
-            if not (bf16 or x6) and self._use_wino4(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
+            forced = self.layer_algo.get(name)       # Winograd guard (calibrate): per-layer demotion
+            if forced == 'direct':
+                pass
+            elif forced == 'winograd' and not (bf16 or x6) and winograd.eligible(ks, st, pad, cin_p, cout_p, ups):
+                wino_off = P.add_weights(winograd.transform_filters(w))
+            elif not (bf16 or x6) and self._use_wino4(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
                 wino_off = P.add_weights(winograd.transform_filters4(w))
                 wino_flag = _lib.TILE_WINO4
             elif not (bf16 or x6) and self._use_wino(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
@@ -590,7 +612,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             nb = m.num_branches
             ys = []
             depth = len(m.branches[0])
-            grouped = (self.group_branches and not (bf16 or x6) and 2 <= nb <= 4
+            grouped = (self._group_on() and not (bf16 or x6) and 2 <= nb <= 4
                        and all(len(br) == depth for br in m.branches)
                        and all(self._use_wino4(3, 1, 1, c.in_channels, c.out_channels, xs[i][1],
                                                xs[i][2], 1)
@@ -728,7 +750,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             self._engine = {}
             self._engine_ver = ver
         key = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
-               self.wino4_min_hw, self.group_branches, self.tile_flags, tuple(sorted(self.tile_overrides.items())))
+               self.wino4_min_hw, self._group_on(), tuple(sorted(self.layer_algo.items())),
+               self.tile_flags, tuple(sorted(self.tile_overrides.items())))
         eng = self._engine.get(key)
         if eng is not None:
             return eng
@@ -755,6 +778,101 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self._engine[key] = eng
         return eng
 
+    # ---- Winograd numerics guard -----------------------------------------------------------
+    def calibrate(self, x, budget=None, demote=True, log=None):
+        """One-batch calibration of the Winograd layers on probe images ``x`` [B,3,H,W] (cuda).
+
+        F(4x4,3x3) with the points {0, +-1, +-2, inf} multiplies by up to 8 in its transforms and
+        amplifies the DC part of its input; with He-initialised weights and O(1) activations that
+        costs a factor ~5 over the direct sum (still float32-class), but nothing guarantees it for
+        a trained checkpoint with wide BatchNorm scales and large post-ReLU means.  This walks the
+        op list ONE LAYER AT A TIME on the engine's own buffers; every Winograd layer is run twice
+        on its real input -- as planned, and on the direct kernel into a scratch buffer -- and its
+        error  rms(winograd - direct) / rms(direct)  is recorded.  Layers above ``budget``
+        (default ``wino_budget``) are demoted -- F(4x4) -> F(2x2) -> direct -- in ``layer_algo``,
+        the plan is rebuilt and the pass repeated until nothing changes.  Every demotion is logged.
+        Returns the report {'layers': [(name, algo, err_rms, err_max)], 'demoted': {...}}."""
+        import logging
+        log = log or logging.getLogger('shapy_amd.hrnet').warning
+        budget = self.wino_budget if budget is None else budget
+        _lib.require_cuda(x, 'images')
+        if self.compute_dtype != 'f32':
+            raise ValueError('calibrate() applies to the float32 path')
+        lib = _lib.load()
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        keep = self.multi_stream, self.group_branches
+        report = None
+        try:
+            self.multi_stream, self.group_branches = False, False       # one op = one launch
+            for _ in range(3):
+                eng = self._compile(H, W, x.device)
+                layers = self._calibrate_pass(lib, eng, x)
+                worst = {}
+                for name, algo, e_rms, e_max in layers:
+                    if e_rms > budget:
+                        worst[name] = 'winograd' if algo == 'winograd4' and winograd.eligible(
+                            3, 1, 1, *self._op_channels(eng, name)) else 'direct'
+                report = {'layers': layers, 'demoted': dict(self.layer_algo), 'budget': budget}
+                if not worst or not demote:
+                    break
+                for name, to in worst.items():
+                    e = next(l for l in layers if l[0] == name)
+                    log(f'Winograd guard: {name}: {e[1]} error {e[2]:.2e} rms-relative '
+                        f'(max {e[3]:.2e}) > budget {budget:.1e} on the probe batch -> {to}')
+                    self.layer_algo[name] = to
+                report['demoted'] = dict(self.layer_algo)
+        finally:
+            self.multi_stream, self.group_branches = keep
+        self.calibration_report = report
+        self._calibrated_ver = self._weights_version()
+        return report
+
+    @staticmethod
+    def _op_channels(eng, name):
+        o = next(o for o in eng['plan'].ops if o.get('name') == name)
+        return o['Cin'], o['Cout']
+
+    def _calibrate_pass(self, lib, eng, x):
+        P, B = eng['plan'], x.shape[0]
+        H, W = x.shape[2], x.shape[3]
+        # scratch output for the direct re-run: one buffer of the largest conv output behind the arena
+        scratch_off = (eng['ws_per_img'] + 7) // 8 * 8
+        biggest = max(o['Ho'] * o['Wo'] * o['ups'] ** 2 * o['Cout'] for o in P.ops if o['type'] == _lib.OP_CONV)
+        ws = torch.empty((scratch_off + biggest) * B, dtype=torch.float32, device=x.device)
+        feat = torch.empty(B, eng['feat_dim'], dtype=torch.float32, device=x.device)
+        one = (_lib.ShapyOp * 1)()
+        out = []
+
+        def run(op):
+            rc = lib.shapy_hrnet_run(op, 1, _lib.ptr(eng['weights']), _lib.ptr(x), _lib.ptr(ws),
+                                     scratch_off + biggest, _lib.ptr(feat), B, H, W, 0, eng['dtype'],
+                                     _lib.current_stream())
+            _lib.check(rc, 'shapy_hrnet_run (calibration)')
+        for i, o in enumerate(P.ops):
+            ctypes.memmove(one, ctypes.byref(eng['ops'][i]), ctypes.sizeof(_lib.ShapyOp))
+            op = one[0]
+            op.barrier_before, op.lane, op.group = 0, 0, 0
+            if o['type'] == _lib.OP_CONV and o.get('wino_off', -1) >= 0:
+                algo = 'winograd4' if o['tile'] & _lib.TILE_WINO4 else 'winograd'
+                keep = op.tile, op.wino_off, op.out_off, op.out_ld, op.out_coff
+                op.tile = (op.tile & ~_lib.TILE_WINO4) | 0x2000         # never Winograd: direct kernel
+                op.wino_off, op.out_off, op.out_ld, op.out_coff = -1, scratch_off, o['Cout'], 0
+                run(one)
+                op.tile, op.wino_off, op.out_off, op.out_ld, op.out_coff = keep
+                run(one)
+                n = B * o['Ho'] * o['Wo']
+                ref = ws[scratch_off * B:scratch_off * B + n * o['Cout']].view(n, o['Cout'])
+                got = ws[o['outb'].off * B:o['outb'].off * B + n * o['out_ld']].view(n, o['out_ld'])[
+                    :, o['out_coff']:o['out_coff'] + o['Cout']]
+                d = (got - ref).double()
+                scale = ref.double().pow(2).mean().sqrt().clamp_min(1e-30)
+                out.append((o['name'], algo, float(d.pow(2).mean().sqrt() / scale),
+                            float(d.abs().max() / ref.abs().max().clamp_min(1e-30))))
+            else:
+                run(one)
+        return out
+
     def _forward_graph(self, lib, eng, x):
         B, _, H, W = x.shape
         key = (B, bool(self.multi_stream))
@@ -777,6 +895,10 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         if H % 32 or W % 32:
             raise ValueError('HRNet input height/width must be multiples of 32')
         x = x.contiguous().float()
+        if (self.wino_guard and self.compute_dtype == 'f32' and self.conv_algo in ('winograd', 'winograd4', 'auto')
+                and self._calibrated_ver != self._weights_version()):
+            self.layer_algo = {}
+            self.calibrate(x[:min(B, 8)])            # a few images are enough to see a layer misbehave
         eng = self._compile(H, W, x.device)
         if self.use_graph is True or (self.use_graph == 'auto' and B <= self.graph_max_batch):
             return {'concat': self._forward_graph(lib, eng, x)}

@@ -565,6 +565,85 @@ def test_hrnet_grouped_branch_launches_equal_per_layer_launches(network, B, size
     assert torch.equal(got, ref) and torch.equal(again, ref)
 
 
+@pytest.mark.parametrize('wino', [True, 4])
+@pytest.mark.parametrize('kind', ['mean3', 'scale100', 'relu_like'])
+def test_winograd_kernels_on_shifted_and_scaled_inputs(wino, kind):
+    """the F(4x4) points {0, +-1, +-2, inf} amplify DC, and the kernel tests only used
+    zero-mean unit-variance operands.  Inputs with a +3 sigma mean, with scale 100, and post-ReLU-like
+    (non-negative, mean ~0.9 sigma): error against float64 RELATIVE TO THE OUTPUT SCALE."""
+    _need_gpu()
+    from shapy_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(7)
+    worst = 0.0
+    for (B, H, W, C, O) in ((2, 56, 56, 48, 48), (2, 28, 28, 96, 96), (2, 14, 14, 192, 192), (4, 7, 7, 384, 384)):
+        x = torch.randn(B, H, W, C, generator=g)
+        x = {'mean3': x + 3.0, 'scale100': 100.0 * x, 'relu_like': torch.relu(x + 0.5)}[kind].cuda()
+        w = (torch.randn(O, 3, 3, C, generator=g) / np.sqrt(9 * C)).cuda()
+        b = torch.randn(O, generator=g).cuda()
+        r = torch.randn(B, H, W, O, generator=g).cuda()
+        y = _conv_call(lib, x, w, b, r, True, 1, 1, wino=wino)
+        ref = _conv_ref(x, w, b, r, True, 1, 1)
+        err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        worst = max(worst, err)
+        # measured on MI355X: F(2x2) <= 9e-7, F(4x4) <= 4e-6 of the output scale on all three kinds
+        assert err < (2e-5 if wino == 4 else 5e-6), (kind, (B, H, W, C, O), err)
+    print(f'winograd F({"4x4" if wino == 4 else "2x2"}) {kind}: worst error / output scale {worst:.2e}')
+
+
+def test_winograd_guard_calibration_and_wide_batchnorm_scales():
+    """The Winograd numerics guard (HighResolutionNet.calibrate, run on the first batch after the
+    weights changed): (1) benign synthetic weights -> every Winograd layer is far inside the budget,
+    nothing is demoted; (2) "wild" weights -- BatchNorm gamma / sigma spread over 10^3 per channel,
+    positive post-ReLU means -- with conv_algo left at its default still meet 1e-4 on the features
+    against the CPU oracle; (3) with an artificially small budget the worst layers ARE demoted
+    (F(4x4) -> F(2x2) -> direct), logged, and the rebuilt plan carries the demotions."""
+    _need_gpu()
+    import sys
+    sys.path.insert(0, osp.join(osp.dirname(osp.dirname(osp.abspath(__file__))), 'tools'))
+    import __graft_entry__ as ge
+    from oracle import hrnet_torch
+    from shapy_amd.utils import synthetic as syn
+    from wino_guard_report import make_wild
+    net, _ = ge.make_network(model_folder='/tmp/shapy_synth_models_guard')
+    bb = net.backbone
+    assert bb.wino_guard and bb.conv_algo == 'winograd4'
+    x = torch.from_numpy(syn.synthetic_images(2, 224, 21)).cuda()
+    with torch.no_grad():
+        bb(x)
+    rep = bb.calibration_report
+    assert rep is not None and len(rep['layers']) > 200 and rep['demoted'] == {}
+    assert max(l[2] for l in rep['layers']) < 0.25 * bb.wino_budget          # measured: 1.3e-6
+    # (2) wide BatchNorm scales
+    make_wild(bb)
+    with torch.no_grad():
+        feat = bb(x)['concat'].cpu()
+    assert bb.calibration_report is not rep                                    # re-calibrated
+    sd = {'backbone.' + k: v.detach().cpu() for k, v in bb.state_dict().items()}
+    torch.set_num_threads(min(torch.get_num_threads(), 32))
+    with torch.no_grad():
+        ref = hrnet_torch.hrnet_forward(sd, x.cpu(), prefix='backbone.')
+    scale = ref.abs().max().item()
+    err = (feat - ref).abs().max().item()
+    print(f'wild weights: feature scale {scale:.3g}, error vs CPU oracle {err:.2e}, demoted {bb.calibration_report["demoted"]}')
+    assert 5.0 < scale < 1e3 and err < 1e-4
+    # (3) the mechanism: a budget below the F(4x4) layers' benign error demotes the worst of them
+    msgs = []
+    rep3 = bb.calibrate(x, budget=6e-7, log=msgs.append)
+    assert rep3['demoted'] and len(msgs) >= len(rep3['demoted'])
+    assert all(v in ('winograd', 'direct') for v in rep3['demoted'].values())
+    eng = bb._compile(224, 224, x.device)
+    for o in eng['plan'].ops:
+        to = rep3['demoted'].get(o.get('name'))
+        if to == 'direct':
+            assert o['wino_off'] < 0
+        elif to == 'winograd':
+            assert o['wino_off'] >= 0 and not (o['tile'] & 0x100000)
+    with torch.no_grad():
+        feat3 = bb(x)['concat'].cpu()
+    assert (feat3 - ref).abs().max().item() < 1e-4
+
+
 def test_conv2d_group_c_abi_matches_single_launches():
     """shapy_conv2d_group through the C-ABI: groups of 1-4 layers incl. partly filled workgroups,
     a channel-offset epilogue, Cout = 144 (the generic XCD split), more tasks than workgroup slots;

@@ -25,14 +25,27 @@ def main():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--algo', default=None)
     ap.add_argument('--verbose', action='store_true')
+    ap.add_argument('--group', type=int, default=None, help='group_branches of the traced run (default: the product default)')
     args = ap.parse_args()
     import torch                                                   # noqa: F401
     import __graft_entry__ as ge
     net, _ = ge.make_network(device='cpu')
     if args.algo:
         net.backbone.conv_algo = args.algo
+    if args.group is not None:
+        net.backbone.group_branches = bool(args.group)
     plan = net.backbone._build_plan(args.size, args.size)
-    ops = plan.ops
+    # one kernel per op, except launch groups (one persistent kernel for `group` ops): the group's
+    # first op stands for the launch
+    ops, skip = [], 0
+    for o in plan.ops:
+        if skip:
+            skip -= 1
+            continue
+        if o.get('group', 0) > 1:
+            skip = o['group'] - 1
+            o = dict(o, name=o.get('name', '') + f' [+{skip} grouped]')
+        ops.append(o)
     f = glob.glob(args.out + '/**/*kernel_trace.csv', recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f))]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
