@@ -142,8 +142,9 @@ enum { SHAPY_OP_CONV = 0, SHAPY_OP_STEM = 1, SHAPY_OP_MEANPOOL = 2 };
 
 typedef struct ShapyOp {
   int32_t type;
-  int32_t lane;                /* independent branch id (0..3): ops of different lanes between
-                                  two barriers may run concurrently                          */
+  int32_t lane;                /* stream id (0..6; 0 = the caller's stream): ops of different
+                                  lanes may run concurrently unless ordered by a barrier or by
+                                  sig / wait                                                 */
   int32_t barrier_before;      /* 1: all lanes must have finished before this op starts     */
   int32_t Hi, Wi, Cin, in_ld, Ho, Wo, Cout, ksize, stride, pad;
   int32_t out_ld, out_coff, res_ld, res_coff, relu, ups, tile;
@@ -151,6 +152,13 @@ typedef struct ShapyOp {
                                   of each other (same lane, same epoch): they are issued as one
                                   shapy_conv2d_group launch when every one is an F(4x4) layer,
                                   otherwise one after the other; 0 / 1 elsewhere             */
+  int32_t sig;                 /* >= 0: event slot (0..63) recorded on this op's stream after it: a
+                                  later op of ANOTHER lane waits for it; -1: none             */
+  int32_t wait[3];             /* event slots to wait for before this op (-1 = unused): its
+                                  producers on other lanes.  Ops of one lane are ordered by the
+                                  lane's stream; lanes 1..6 are side streams, 0 the caller's.
+                                  With sig / wait a plan needs barrier_before only where it
+                                  wants every lane joined (slots are reused after a barrier)   */
   int64_t in_off, out_off, res_off;     /* per-image float offsets into the workspace; -1 = none;
                                             in_off == -2: the network input (STEM)           */
   int64_t wgt_off, bias_off;            /* float offsets into the weight blob; -1 = none     */

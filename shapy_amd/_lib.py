@@ -39,6 +39,7 @@ class ShapyOp(ctypes.Structure):
                 ('Cout', i32), ('ksize', i32), ('stride', i32), ('pad', i32),
                 ('out_ld', i32), ('out_coff', i32), ('res_ld', i32), ('res_coff', i32),
                 ('relu', i32), ('ups', i32), ('tile', i32), ('group', i32),
+                ('sig', i32), ('wait', i32 * 3),
                 ('in_off', i64), ('out_off', i64), ('res_off', i64),
                 ('wgt_off', i64), ('bias_off', i64), ('wino_off', i64)]
 

@@ -1,5 +1,7 @@
 // HRNet op-list executor + the two non-GEMM kernels of the backbone (stem conv, spatial mean).
 // Reference: regressor/human_shape/models/backbone/hrnet.py:426-498.
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "common.h"
@@ -13,6 +15,21 @@ __device__ __forceinline__ void store_elem(unsigned short *p, float v) {
   unsigned u = __float_as_uint(v);
   u += 0x7fffu + ((u >> 16) & 1u);                      // bf16, round to nearest even
   *p = (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void store_row8(float *p, const float (&r)[8]) {
+  reinterpret_cast<f32x4 *>(p)[0] = f32x4{r[0], r[1], r[2], r[3]};
+  reinterpret_cast<f32x4 *>(p)[1] = f32x4{r[4], r[5], r[6], r[7]};
+}
+__device__ __forceinline__ void store_row8(unsigned short *p, const float (&r)[8]) {
+  u32x4 x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned lo = __float_as_uint(r[2 * e]), hi = __float_as_uint(r[2 * e + 1]);
+    lo += 0x7fffu + ((lo >> 16) & 1u);                  // bf16, round to nearest even
+    hi += 0x7fffu + ((hi >> 16) & 1u);
+    x[e] = (lo >> 16) | (hi & 0xffff0000u);
+  }
+  *reinterpret_cast<u32x4 *>(p) = x;
 }
 __device__ __forceinline__ float load_elem(const float *p) { return *p; }
 __device__ __forceinline__ float load_elem(const unsigned short *p) {
@@ -59,9 +76,18 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float *__restrict_
       }
     }
   }
+  // the 8 channels of a thread as 16-byte stores (8 lanes = the pixel's whole 256-byte row; scalar
+  // stores wrote 4-byte pieces: 175 us for the 205 MB of B = 64, a 60 us job at HBM speed)
   OutT *o = out + pix * out_ld + g * 8;
+  float r[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) store_elem(o + i, fmaxf(acc[i] + bias[g * 8 + i], 0.f));
+  for (int i = 0; i < 8; ++i) r[i] = fmaxf(acc[i] + bias[g * 8 + i], 0.f);
+  if ((out_ld & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    store_row8(o, r);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) store_elem(o + i, r[i]);
+  }
 }
 
 // ---- spatial mean over H*W (hrnet.py:484) ----
@@ -79,10 +105,13 @@ __global__ void mean_pool_kernel(const InT *__restrict__ in, float *__restrict__
 }
 
 // ---- side streams for the independent branches of a HighResolutionModule ----
+constexpr int N_SIDE = 6;        // side streams: lanes 1..3 = branches, 4..6 = auxiliary chains
+constexpr int N_EVENTS = 64;     // dependency events (ShapyOp.sig / .wait), reused from epoch to epoch
 struct Lanes {
-  hipStream_t s[3] = {nullptr, nullptr, nullptr};
+  hipStream_t s[N_SIDE] = {};
   hipEvent_t fork = nullptr;
-  hipEvent_t join[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t join[N_SIDE] = {};
+  hipEvent_t ev[N_EVENTS] = {};
   bool ready = false;
 };
 static Lanes g_lanes[16];
@@ -95,11 +124,23 @@ static int get_lanes(Lanes **out) {
   std::lock_guard<std::mutex> lk(g_lanes_mu);
   Lanes &L = g_lanes[dev];
   if (!L.ready) {
-    for (int i = 0; i < 3; ++i) {
-      SHAPY_HIP_TRY(hipStreamCreateWithFlags(&L.s[i], hipStreamNonBlocking));
+    // (SHAPY_LANE_PRIO=0 turns it off; +1.1..1.6 % end to end, run T of round 3) side lane i (the branch with the smaller maps = the longer chain
+    // of latency-bound launches) gets a higher stream priority than lane i - 1
+    static const int prio_mode = getenv("SHAPY_LANE_PRIO") ? atoi(getenv("SHAPY_LANE_PRIO")) : 1;
+    int plo = 0, phi = 0;
+    SHAPY_HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi));      // phi = highest (numerically lowest)
+    for (int i = 0; i < N_SIDE; ++i) {
+      if (prio_mode) {
+        int pr = plo - (i % 3 + 1);
+        if (pr < phi) pr = phi;
+        SHAPY_HIP_TRY(hipStreamCreateWithPriority(&L.s[i], hipStreamNonBlocking, pr));
+      } else
+        SHAPY_HIP_TRY(hipStreamCreateWithFlags(&L.s[i], hipStreamNonBlocking));
       SHAPY_HIP_TRY(hipEventCreateWithFlags(&L.join[i], hipEventDisableTiming));
     }
     SHAPY_HIP_TRY(hipEventCreateWithFlags(&L.fork, hipEventDisableTiming));
+    for (int i = 0; i < N_EVENTS; ++i)
+      SHAPY_HIP_TRY(hipEventCreateWithFlags(&L.ev[i], hipEventDisableTiming));
     L.ready = true;
   }
   *out = &L;
@@ -122,9 +163,9 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
     int rc = get_lanes(&L);
     if (rc) return rc;
   }
-  bool forked[3] = {false, false, false}, dirty[3] = {false, false, false};
+  bool forked[N_SIDE] = {}, dirty[N_SIDE] = {};
   auto join_all = [&]() -> int {
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < N_SIDE; ++i)
       if (dirty[i]) {
         SHAPY_HIP_TRY(hipEventRecord(L->join[i], L->s[i]));
         SHAPY_HIP_TRY(hipStreamWaitEvent(main, L->join[i], 0));
@@ -140,7 +181,7 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
       if (o.barrier_before) {
         int rc = join_all();
         if (rc) return rc;
-        forked[0] = forked[1] = forked[2] = false;
+        for (int i = 0; i < N_SIDE; ++i) forked[i] = false;
         // The fork point of the new epoch is HERE, before any of its ops is enqueued on the main
         // stream.  (Round 2 recorded it lazily at the first side-lane op -- in plan order that
         // comes after the main lane's own ops of the epoch, so the side lanes waited for those
@@ -148,7 +189,7 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
         SHAPY_HIP_TRY(hipEventRecord(L->fork, main));
         fork_recorded = true;
       }
-      if (o.lane > 0 && o.lane <= 3) {
+      if (o.lane > 0 && o.lane <= N_SIDE) {
         const int li = o.lane - 1;
         if (!forked[li]) {
           if (!fork_recorded) {
@@ -162,6 +203,15 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
         dirty[li] = true;
       }
     }
+    // explicit dependencies on ops of OTHER lanes (the plan's happens-before graph: ops of one lane
+    // are ordered by their stream): wait for the producers' events before this op ...
+    if (multi_stream)
+      for (int w = 0; w < 3; ++w)
+        if (o.wait[w] >= 0) {
+          if (o.wait[w] >= N_EVENTS) return SHAPY_EINVAL;
+          SHAPY_HIP_TRY(hipStreamWaitEvent(s, L->ev[o.wait[w]], 0));
+        }
+    const int idx_first = idx;
     auto buf = [&](int64_t off) -> char * {
       return off < 0 ? nullptr : (char *)ws + off * (int64_t)B * esz;
     };
@@ -236,6 +286,13 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
     } else {
       return SHAPY_EINVAL;
     }
+    // ... and signal this op's own event when a later op of another lane waits for it
+    if (multi_stream)
+      for (int q = idx_first; q <= idx; ++q)
+        if (ops[q].sig >= 0) {
+          if (ops[q].sig >= N_EVENTS) return SHAPY_EINVAL;
+          SHAPY_HIP_TRY(hipEventRecord(L->ev[ops[q].sig], s));
+        }
   }
   if (multi_stream) {
     int rc = join_all();

@@ -143,12 +143,13 @@ class HighResolutionModule(_Container):
 # plan builder
 # ------------------------------------------------------------------------------------------
 class _Buf:
-    __slots__ = ('H', 'W', 'C', 'size', 'uses', 'off')
+    __slots__ = ('H', 'W', 'C', 'size', 'uses', 'off', 'acc')
 
     def __init__(self, H, W, C):
         self.H, self.W, self.C = H, W, C
         self.size = H * W * C
-        self.uses = []        # (epoch, lane, op index)
+        self.uses = []        # (epoch, lane, time index) of every op that touches the buffer
+        self.acc = []         # (op index, is_write, first channel, end channel)
         self.off = None
 
 
@@ -183,6 +184,7 @@ class _Plan:
         self.wbytes = 0
         self.epoch = 0
         self._pending_barrier = False
+        self.no_barriers = False
         self._group_left = 0   # ops still to come in the current launch group
         self._group_t = 0      # ... and the group's time index (= op index of its first op)
 
@@ -198,7 +200,9 @@ class _Plan:
         return b
 
     def barrier(self):
-        self._pending_barrier = True
+        # (event-driven plans order the lanes by data dependencies alone: no joins)
+        if not self.no_barriers:
+            self._pending_barrier = True
 
     def add_weights(self, arr, as_bf16=False):
         """Appends a tensor to the weight blob; returns its offset in ELEMENTS of its own type
@@ -250,37 +254,128 @@ class _Plan:
             b = kw.get(key)
             if b is not None:
                 b.uses.append((self.epoch, kw['lane'], t))
+        # data dependencies on earlier ops: read-after-write on the channels read (input: all,
+        # residual: the output's slice), write-after-read / -write on the slice written
+        i, deps = len(self.ops), set()
+        acc = []
+        if kw.get('inb') is not None:
+            acc.append((kw['inb'], False, 0, kw['inb'].C))
+        if kw.get('resb') is not None:
+            acc.append((kw['resb'], False, kw['res_coff'], kw['res_coff'] + kw['Cout']))
+        if kw.get('outb') is not None:
+            acc.append((kw['outb'], True, kw['out_coff'], kw['out_coff'] + kw['Cout']))
+        for b, is_w, c0, c1 in acc:
+            for (j, w, a0, a1) in b.acc:
+                if j != i and (is_w or w) and a0 < c1 and c0 < a1:
+                    deps.add(j)
+        for b, is_w, c0, c1 in acc:
+            b.acc.append((i, is_w, c0, c1))
+        kw['deps'] = deps
         self.ops.append(kw)
 
-    def allocate(self):
-        """Liveness packing of the activation workspace (floats per image).
+    def _walk(self):
+        """Yields (first op index, member indices, mask implied by lane order and barriers) per
+        launch: single ops and launch groups (whose members run concurrently), in plan order.
+        Needs hb of earlier ops: used by happens_before / sync_plan while they fill it."""
+        n, i = len(self.ops), 0
+        lane_tail, barrier_mask = {}, 0
+        while i < n:
+            o = self.ops[i]
+            g = max(1, o['group'])
+            members = list(range(i, i + g))
+            assert all(self.ops[k]['lane'] == o['lane'] for k in members)
+            assert not any(self.ops[k]['barrier_before'] for k in members[1:])
+            if o['barrier_before']:
+                barrier_mask = (1 << i) - 1
+            implied = barrier_mask | lane_tail.get(o['lane'], 0)
+            yield i, members, implied
+            tail = 0
+            for k in members:
+                tail |= self.hb[k] | (1 << k)
+            lane_tail[o['lane']] = tail
+            i += g
 
-        Ops of different lanes inside one epoch (= between two barriers) run concurrently on
-        different HIP streams, so a buffer touched from several lanes or epochs is live for
-        its whole [first epoch, last epoch] interval.  Buffers confined to ONE (epoch, lane)
-        -- the temporaries of a residual-block chain -- are packed by op order inside a
-        per-(epoch, lane) arena, which is itself live only during that epoch."""
-        used = [b for b in self.bufs if b.uses]
-        groups, global_items = {}, []
-        for b in used:
-            keys = {(e, l) for e, l, _ in b.uses}
-            if len(keys) == 1:
-                groups.setdefault(next(iter(keys)), []).append(b)
-            else:
-                es = [e for e, _, _ in b.uses]
-                global_items.append((min(es), max(es), b.size, b))
-        arenas = []
-        for (e, l), bs in groups.items():
-            arena = _Buf(0, 0, 0)
-            arena.size = _pack([(min(u[2] for u in b.uses), max(u[2] for u in b.uses), b.size, b)
-                                for b in bs])
-            arenas.append((arena, bs))
-            global_items.append((e, e, arena.size, arena))
-        total = _pack(global_items)
-        for arena, bs in arenas:
-            for b in bs:
-                b.off += arena.off
-        return total
+    def happens_before(self):
+        """hb[i] = bit set of the ops that are guaranteed to have FINISHED when op i starts, under
+        the executor's rules (csrc/hrnet_ops.hip): the ops of a lane run in plan order on the
+        lane's stream (an op behind a launch group follows all its members); a barrier joins every
+        lane (everything before it precedes everything after it); an op waits for the events of
+        its data dependencies on other lanes; the members of a launch group run concurrently."""
+        self.hb = [0] * len(self.ops)
+        for _, members, implied in self._walk():
+            for k in members:
+                m = implied
+                for d in self.ops[k]['deps']:
+                    assert d not in members, 'members of a launch group must be independent'
+                    m |= self.hb[d] | (1 << d)
+                self.hb[k] = m
+        return self.hb
+
+    def sync_plan(self, max_events=64):
+        """Event slots for the executor: per op `sig` (slot to record after it, or -1) and `wait`
+        (<= 3 slots to wait for before it) = the op's dependencies on OTHER lanes that are not
+        already implied by its lane order, a barrier or another of its dependencies."""
+        n = len(self.ops)
+        self.hb = [0] * n
+        waits = [[] for _ in range(n)]
+        for _, members, implied in self._walk():
+            for k in members:
+                o = self.ops[k]
+                m = implied
+                for d in o['deps']:
+                    m |= self.hb[d] | (1 << d)
+                self.hb[k] = m
+                cross = sorted(d for d in o['deps']
+                               if self.ops[d]['lane'] != o['lane'] and not (implied >> d) & 1)
+                need = [d for d in cross if not any(d2 != d and (self.hb[d2] >> d) & 1 for d2 in cross)]
+                if len(need) > 3:
+                    raise ValueError(f"op {k} ({o.get('name')}) waits for {len(need)} lanes")
+                waits[k] = need
+        # slots: an event is free again once its last waiter has been enqueued (plan order)
+        last_waiter = {}
+        for i, w in enumerate(waits):
+            for d in w:
+                last_waiter[d] = i
+        free, busy, sig = list(range(max_events)), [], [-1] * n
+        for i in range(n):
+            busy.sort()
+            while busy and busy[0][0] < i:
+                free.append(busy.pop(0)[1])
+            if i in last_waiter:
+                if not free:
+                    raise ValueError('out of dependency events')
+                sig[i] = free.pop(0)
+                busy.append((last_waiter[i], sig[i]))
+        for i, o in enumerate(self.ops):
+            o['sig'] = sig[i]
+            o['wait'] = [sig[d] for d in waits[i]] + [-1] * (3 - len(waits[i]))
+        return waits
+
+    def allocate(self):
+        """Packing of the activation workspace (floats per image) under the plan's happens-before
+        order: two buffers may share memory iff EVERY op that touches one has finished before ANY op
+        that touches the other starts (lane order, barriers, dependency events: `happens_before`).
+        First fit in order of first use."""
+        hb = self.happens_before()
+        used = [b for b in self.bufs if b.acc]
+        touch = {id(b): sorted({j for (j, _, _, _) in b.acc}) for b in used}
+        mask = {id(b): sum(1 << j for j in touch[id(b)]) for b in used}
+
+        def before(a, b):          # every use of a precedes every use of b
+            ma = mask[id(a)]
+            return all((hb[v] & ma) == ma for v in touch[id(b)])
+        placed, total = [], 0
+        for b in sorted(used, key=lambda b: (touch[id(b)][0], -b.size)):
+            conflicts = sorted((p.off, p.size) for p in placed if not (before(p, b) or before(b, p)))
+            off = 0
+            for (o, sz) in conflicts:
+                if off + b.size <= o:
+                    break
+                off = max(off, (o + sz + 7) // 8 * 8)      # aligned BEFORE the next gap test
+            b.off = off
+            placed.append(b)
+            total = max(total, off + b.size)
+        return (total + 7) // 8 * 8
 
 
 def _fold(conv, bn):
@@ -390,6 +485,11 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: Winograd numerics guard: per-layer demotions {op name: 'winograd' (F(2x2)) | 'direct'} found
         #: by ``calibrate`` for the CURRENT weights; wino_guard = run the calibration on the first
         #: float32 batch after the weights changed (SHAPY_WINO_GUARD=0 disables)
+        #: multi-stream plans: explicit dependencies (events) instead of a join between the branches
+        #: and the fuse layers of a module, fuse chains on auxiliary lanes (SHAPY_DAG=0: round-2 plan)
+        self.dag = os.environ.get('SHAPY_DAG', '1') != '0'
+        self.dag_aux = os.environ.get('SHAPY_DAG_AUX', '0') == '1'
+        self.dag_no_barriers = os.environ.get('SHAPY_DAG_NO_BARRIERS', '0') == '1'
         self.layer_algo = {}
         self.wino_guard = os.environ.get('SHAPY_WINO_GUARD', '1') != '0'
         self.wino_budget = 2e-5          # rms(winograd - direct) / rms(direct) per layer
@@ -510,6 +610,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         st['_ver_tensors'] = None
         return st
 
+    _dag_eff = False
+
     def _group_on(self):
         g = self.group_branches
         return (not self.multi_stream) if g == 'auto' else bool(g)
@@ -525,6 +627,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
 
     def _build_plan(self, H, W, bf16=False, x6=False):
         P = _Plan(bf16, x6)
+        P.no_barriers = bool(self._dag_eff and self.dag_no_barriers and not self._group_on())
         ov = self.tile_overrides
         if self.conv_algo not in ('direct', 'winograd', 'winograd4', 'auto'):
             raise ValueError(f'unknown conv_algo {self.conv_algo!r}')
@@ -649,7 +752,33 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                         x, _, _ = conv(blk.conv2, blk.bn2, t, Hc, Wc, res=x, relu=True, lane=i,
                                        name=f'{name}.branches.{i}.{bi}.conv2')
                     ys.append((x, Hc, Wc))
-            P.barrier()
+            # dag: no join between the branches and the fuse layers -- every fuse conv waits for
+            # exactly the tensors it reads (events, _Plan.sync_plan) -- and the leading convs of the
+            # stride-2 chains (fuse_layers[i][j], i - j >= 2) run on auxiliary lanes 4..6, so that
+            # the output of the smallest map no longer queues six convs on one stream
+            dag = self._dag_eff and not grouped
+            if not dag:
+                P.barrier()
+            aux = [0]
+            lead = {}                       # (i, j) -> (tensor, H, W) behind the chain's leading convs
+            if dag:
+                # enqueue order = stream order: the leading convs of the stride-2 chains first, so
+                # that they sit in front of their lane's accumulating convs (which wait for the
+                # OTHER branches)
+                for i in range(len(m.fuse_layers)):
+                    for j in range(i - 1):
+                        fl = m.fuse_layers[i][j]
+                        # on the lane of their SOURCE branch (free as soon as that branch is
+                        # done), or on an auxiliary stream (dag_aux: measured slower -- HIP
+                        # multiplexes streams onto 4 hardware queues, with 7 streams the lanes
+                        # serialise: 16.9 vs 13.0 ms per step, run V of round 3)
+                        chain_lane = 4 + aux[0] % 3 if self.dag_aux else j
+                        aux[0] += 1
+                        t, Ht, Wt = ys[j]
+                        for k in range(i - j - 1):
+                            t, Ht, Wt = conv(fl[k][0], fl[k][1], t, Ht, Wt, relu=True,
+                                             lane=chain_lane, name=f'{name}.fuse_layers.{i}.{j}.{k}')
+                        lead[(i, j)] = (t, Ht, Wt)
             outs = []
             for i in range(len(m.fuse_layers)):
                 xi, Hi_, Wi_ = ys[i]
@@ -671,8 +800,9 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                              ups=2 ** (j - i), lane=i, out_ld=o_ld, out_coff=o_co, res_ld=r_ld,
                              res_coff=r_co, name=nm)
                     else:
-                        t, Ht, Wt = xj, Hj, Wj
-                        for k in range(i - j):
+                        t, Ht, Wt = lead.get((i, j), (xj, Hj, Wj))
+                        k0 = i - j - 1 if (i, j) in lead else 0
+                        for k in range(k0, i - j):
                             if k == i - j - 1:
                                 conv(fl[k][0], fl[k][1], t, Ht, Wt, outb=outb, res=res, relu=last,
                                      lane=i, out_ld=o_ld, out_coff=o_co, res_ld=r_ld,
@@ -741,7 +871,10 @@ class HighResolutionNet(VersionedWeights, nn.Module):
              res_ld=0, res_coff=0, relu=0, ups=1, tile=0, wgt_off=-1, bias_off=-1, wino_off=-1)
         return P
 
-    def _compile(self, H, W, device):
+    def _compile(self, H, W, device, graph=False):
+        # event-driven plan: eager multi-stream forwards only (capturing it into a hipGraph segfaults
+        # inside graph creation on ROCm 7.2; the captured plan keeps the barrier form)
+        self._dag_eff = bool(self.dag and self.multi_stream and not graph)
         if self.compute_dtype not in ('f32', 'f32x6', 'bf16'):
             raise ValueError(f'unknown compute_dtype {self.compute_dtype!r}')
         bf16 = self.compute_dtype == 'bf16'
@@ -750,12 +883,14 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             self._engine = {}
             self._engine_ver = ver
         key = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
-               self.wino4_min_hw, self._group_on(), tuple(sorted(self.layer_algo.items())),
+               self.wino4_min_hw, self._group_on(), self._dag_eff, self.dag_aux, self.dag_no_barriers,
+               tuple(sorted(self.layer_algo.items())),
                self.tile_flags, tuple(sorted(self.tile_overrides.items())))
         eng = self._engine.get(key)
         if eng is not None:
             return eng
         P = self._build_plan(H, W, bf16, self.compute_dtype == 'f32x6')
+        P.sync_plan()
         ws_per_img = P.allocate()
         n = len(P.ops)
         arr = (_lib.ShapyOp * n)()
@@ -763,8 +898,10 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             a = arr[i]
             for f in ('type', 'lane', 'barrier_before', 'Hi', 'Wi', 'Cin', 'in_ld', 'Ho', 'Wo',
                       'Cout', 'ksize', 'stride', 'pad', 'out_ld', 'out_coff', 'res_ld', 'res_coff',
-                      'relu', 'ups', 'tile', 'group', 'wgt_off', 'bias_off', 'wino_off'):
+                      'relu', 'ups', 'tile', 'group', 'sig', 'wgt_off', 'bias_off', 'wino_off'):
                 setattr(a, f, int(o[f]))
+            for q in range(3):
+                a.wait[q] = int(o['wait'][q])
             a.in_off = -2 if o['type'] == _lib.OP_STEM else o['inb'].off
             a.out_off = -1 if o['outb'] is None else o['outb'].off
             a.res_off = -1 if o['resb'] is None else o['resb'].off
@@ -899,8 +1036,9 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 and self._calibrated_ver != self._weights_version()):
             self.layer_algo = {}
             self.calibrate(x[:min(B, 8)])            # a few images are enough to see a layer misbehave
-        eng = self._compile(H, W, x.device)
-        if self.use_graph is True or (self.use_graph == 'auto' and B <= self.graph_max_batch):
+        use_graph = self.use_graph is True or (self.use_graph == 'auto' and B <= self.graph_max_batch)
+        eng = self._compile(H, W, x.device, graph=use_graph)
+        if use_graph:
             return {'concat': self._forward_graph(lib, eng, x)}
         need = eng['ws_per_img'] * B * eng['esz']
         if eng['ws'] is None or eng['ws'].numel() < need:

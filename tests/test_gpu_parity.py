@@ -644,6 +644,33 @@ def test_winograd_guard_calibration_and_wide_batchnorm_scales():
     assert (feat3 - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize('B,size,graph', [(3, 96, False), (64, 224, False), (2, 224, True)])
+def test_hrnet_event_driven_plan_equals_barrier_plan(network, B, size, graph):
+    """dag (default): dependency events between the lanes instead of a join between the branches and
+    the fuse layers of every module, fuse chains on auxiliary streams -- the same launches on the
+    same (differently packed) buffers: bit-identical features, three forwards in a row (the events
+    are reused), eager and captured."""
+    from shapy_amd.utils import synthetic as syn
+    bb = network.backbone
+    keep = bb.dag, bb.multi_stream, bb.use_graph
+    x = torch.from_numpy(syn.synthetic_images(B, size, 12)).cuda()
+    try:
+        bb.multi_stream, bb.use_graph = True, graph
+        bb.dag = False
+        with torch.no_grad():
+            ref = bb(x)['concat'].clone()
+        bb.dag = True
+        with torch.no_grad():
+            got = [bb(x)['concat'].clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        if not graph:        # (captured plans keep the barrier form)
+            plan = [e for k, e in bb._engine.items() if k[8] is True and k[0] == size][-1]['plan']
+            assert sum(1 for o in plan.ops if o['sig'] >= 0) > 20
+    finally:
+        bb.dag, bb.multi_stream, bb.use_graph = keep
+    assert all(torch.equal(g, ref) for g in got)
+
+
 def test_conv2d_group_c_abi_matches_single_launches():
     """shapy_conv2d_group through the C-ABI: groups of 1-4 layers incl. partly filled workgroups,
     a channel-offset epilogue, Cout = 144 (the generic XCD split), more tasks than workgroup slots;

@@ -109,35 +109,86 @@ def test_plan_macs_match_survey(hrnet):
     assert abs(2 * macs256 / 1e9 - 48.239) < 0.01
 
 
-def test_plan_buffers_never_alias_while_live(hrnet):
-    """Replays the op list with the executor's concurrency model: inside an epoch, ops of
-    different lanes are unordered.  A buffer being written must not overlap any other buffer
-    that is still live (written earlier and read later, or touched in the same epoch by
-    another lane)."""
-    P = hrnet._build_plan(64, 64)
-    total = P.allocate()
-    bufs = [b for b in P.bufs if b.uses]
-    for b in bufs:
-        assert b.off % 4 == 0 and b.off + b.size <= total
-    epoch_of, e = [], 0
-    for o in P.ops:
+def _executor_order(ops):
+    """Reachability enforced by csrc/hrnet_ops.hip for a compiled op list, re-derived from what the
+    executor itself sees (lane, barrier_before, group, sig, wait) -- NOT from the plan's own
+    dependency sets: reach[v] = bit set of the ops that have finished when v starts."""
+    n = len(ops)
+    reach = [0] * n
+    lane_tail, barrier_mask, ev = {}, 0, {}
+    i = 0
+    while i < n:
+        o = ops[i]
+        g = max(1, o['group'])
+        members = range(i, i + g)
         if o['barrier_before']:
-            e += 1
-        epoch_of.append(e)
-    # live interval of a buffer in (epoch, lane, op) terms
-    for i, a in enumerate(bufs):
-        for b in bufs[i + 1:]:
-            if a.off + a.size <= b.off or b.off + b.size <= a.off:
+            barrier_mask, ev = (1 << i) - 1, dict(ev)
+        base = barrier_mask | lane_tail.get(o['lane'], 0)
+        for w in o['wait']:                      # waits are issued once, before the (group) launch
+            if w >= 0:
+                base |= ev[w]
+        tail = 0
+        for k in members:
+            reach[k] = base
+            tail |= base | (1 << k)
+        for k in members:
+            if ops[k]['sig'] >= 0:
+                ev[ops[k]['sig']] = tail if g > 1 else reach[k] | (1 << k)
+        lane_tail[o['lane']] = tail
+        i += g
+    return reach
+
+
+@pytest.mark.parametrize('dag,group,aux', [(True, False, False), (True, False, True), (True, False, 'nobar'),
+                                           (False, False, False), (False, True, False)])
+def test_plan_orders_every_memory_hazard(hrnet, dag, group, aux):
+    """The executor's order (lanes, barriers, dependency events, launch groups) covers every hazard
+    of the PACKED workspace: whenever two ops touch overlapping memory and at least one of them
+    writes, one of them has finished before the other starts.  Checked for the event-driven plan
+    (dag), the round-2 barrier plan and the grouped single-stream plan."""
+    keep = hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw
+    try:
+        hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw = dag, group, 'winograd4', 7
+        hrnet.dag_aux, hrnet.dag_no_barriers = aux is True, aux == 'nobar'
+        P = hrnet._build_plan(224, 224)
+        waits = P.sync_plan()
+        total = P.allocate()
+    finally:
+        hrnet.dag_aux = hrnet.dag_no_barriers = False
+        hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw = keep
+    ops = P.ops
+    reach = _executor_order(ops)
+    if dag:
+        assert sum(1 for w in waits if w) > 50 and sum(o['barrier_before'] for o in ops) < 20
+    if aux == 'nobar':
+        assert sum(o['barrier_before'] for o in ops) == 0
+    # memory accesses: (op, write?, first float, end float, channel window inside a pixel row)
+    acc = []
+    for i, o in enumerate(ops):
+        for key, is_w, c0, cn in (('inb', False, 0, None), ('resb', False, o['res_coff'], o['Cout']),
+                                  ('outb', True, o['out_coff'], o['Cout'])):
+            b = o.get(key)
+            if b is None:
                 continue
-            ea = sorted(a.uses); eb = sorted(b.uses)
-            ka = {(u[0], u[1]) for u in a.uses}; kb = {(u[0], u[1]) for u in b.uses}
-            if len(ka) == 1 and ka == kb:
-                # same (epoch, lane): ordered by op index on one stream
-                assert max(u[2] for u in a.uses) < min(u[2] for u in b.uses) or \
-                    max(u[2] for u in b.uses) < min(u[2] for u in a.uses)
-            else:
-                assert ea[-1][0] < eb[0][0] or eb[-1][0] < ea[0][0], (a.uses, b.uses)
-    assert total * 4 / 1e6 < 3.0            # MB per 64x64 image: liveness packing works
+            assert b.off % 4 == 0 and b.off + b.size <= total
+            acc.append((i, is_w, b.off, b.off + b.size, id(b), c0, c0 + (b.C if cn is None else cn)))
+    acc.sort(key=lambda a: a[2])
+    checked = 0
+    for x in range(len(acc)):
+        i, wi, s0, e0, bi, ci0, ci1 = acc[x]
+        for y in range(x + 1, len(acc)):
+            j, wj, s1, e1, bj, cj0, cj1 = acc[y]
+            if s1 >= e0:
+                break
+            if i == j or not (wi or wj):
+                continue
+            if bi == bj and not (ci0 < cj1 and cj0 < ci1):
+                continue                                  # disjoint channel slices of one buffer
+            u, v = min(i, j), max(i, j)
+            assert (reach[v] >> u) & 1, (ops[u].get('name'), ops[v].get('name'), ops[u]['lane'], ops[v]['lane'])
+            checked += 1
+    assert checked > 1000
+    assert total * 4 / 1e6 < 20.0            # MB per 224x224 image: packing works (no reuse: 112 MB)
 
 
 def test_bn_fold_matches_conv_bn_eval():

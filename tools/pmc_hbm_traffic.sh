@@ -7,6 +7,8 @@ OUT=$1; DT=${2:-f32}; ALGO=${3:-winograd}; BATCH=${4:-64}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
+# one launch per layer and no calibration pass: FORWARDS x 333 conv launches, nothing else
+export SHAPY_WINO_GUARD=0 SHAPY_GROUP_BRANCHES=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $grp | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d "$ROOT/$OUT/$tag" -- \

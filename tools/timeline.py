@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--algo', default=None)
     ap.add_argument('--verbose', action='store_true')
+    ap.add_argument('--no-dag', action='store_true', help='the traced run used SHAPY_DAG=0 or --single-stream')
     ap.add_argument('--group', type=int, default=None, help='group_branches of the traced run (default: the product default)')
     args = ap.parse_args()
     import torch                                                   # noqa: F401
@@ -34,6 +35,7 @@ def main():
         net.backbone.conv_algo = args.algo
     if args.group is not None:
         net.backbone.group_branches = bool(args.group)
+    net.backbone._dag_eff = net.backbone.dag and not args.no_dag        # the traced run: eager, multi-stream
     plan = net.backbone._build_plan(args.size, args.size)
     # one kernel per op, except launch groups (one persistent kernel for `group` ops): the group's
     # first op stands for the launch
