@@ -693,7 +693,7 @@ def main():
     ap.add_argument('--meshes', type=int, default=1000, help='meshes per GPU (measurements)')
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--query-faces', type=int, default=700, help='bvh: query triangles per pair')
-    ap.add_argument('--max-collisions', type=int, default=32, help='bvh: hits kept per query triangle')
+    ap.add_argument('--max-collisions', type=int, default=64, help='bvh: hits kept per query triangle')
     ap.add_argument('--no-cpu-baseline', action='store_true',
                     help='skip the CPU oracle (cpu_baseline and parity fields)')
     ap.add_argument('--single-stream', action='store_true')

@@ -490,6 +490,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.dag = os.environ.get('SHAPY_DAG', '1') != '0'
         self.dag_aux = os.environ.get('SHAPY_DAG_AUX', '0') == '1'
         self.dag_no_barriers = os.environ.get('SHAPY_DAG_NO_BARRIERS', '0') == '1'
+        self.dag_balance = os.environ.get('SHAPY_DAG_BALANCE', '0') == '1'
         self.layer_algo = {}
         self.wino_guard = os.environ.get('SHAPY_WINO_GUARD', '1') != '0'
         self.wino_budget = 2e-5          # rms(winograd - direct) / rms(direct) per layer
@@ -629,6 +630,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         P = _Plan(bf16, x6)
         P.no_barriers = bool(self._dag_eff and self.dag_no_barriers and not self._group_on())
         ov = self.tile_overrides
+        lane_load = {}
         if self.conv_algo not in ('direct', 'winograd', 'winograd4', 'auto'):
             raise ValueError(f'unknown conv_algo {self.conv_algo!r}')
 
@@ -659,6 +661,13 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 wino_flag = _lib.TILE_WINO4
             elif not (bf16 or x6) and self._use_wino(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
                 wino_off = P.add_weights(winograd.transform_filters(w))
+            # rough cost of the launch under the usual four-stream contention (us): picks the lane of
+            # the fuse chains' leading convs (module(): least loaded lane)
+            # (timeline at B = 64: every branch conv of a module takes 105-150 us whatever its map
+            # size -- the small maps are latency-bound chains --, the direct layers 15 us + 45 TFLOP/s)
+            macs = Ho * Wo * cout_p * cin_p * ks * ks
+            lane_load[lane] = lane_load.get(lane, 0.0) + (
+                110.0 if wino_off >= 0 else 15.0 + 2.0 * 64 * macs / 45e6)
             P.op(type=_lib.OP_CONV, lane=lane, inb=inb, outb=outb, resb=res, Hi=Hi, Wi=Wi, Cin=cin_p,
                  in_ld=inb.C, Ho=Ho, Wo=Wo, Cout=cout_p, ksize=ks, stride=st, pad=pad,
                  out_ld=out_ld or outb.C, out_coff=out_coff,
@@ -714,6 +723,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             """xs: list of (buf, H, W).  HighResolutionModule.forward (hrnet.py:175-193)."""
             nb = m.num_branches
             ys = []
+            lane_load.clear()               # per module: the choice below balances THIS module's lanes
             depth = len(m.branches[0])
             grouped = (self._group_on() and not (bf16 or x6) and 2 <= nb <= 4
                        and all(len(br) == depth for br in m.branches)
@@ -772,7 +782,17 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                         # done), or on an auxiliary stream (dag_aux: measured slower -- HIP
                         # multiplexes streams onto 4 hardware queues, with 7 streams the lanes
                         # serialise: 16.9 vs 13.0 ms per step, run V of round 3)
-                        chain_lane = 4 + aux[0] % 3 if self.dag_aux else j
+                        if self.dag_aux:
+                            chain_lane = 4 + aux[0] % 3
+                        elif self.dag_balance:
+                            # ... or on the branch lane with the least work so far (the 56x56
+                            # branch's lane carried the heads of BOTH long chains: 4.0 of the
+                            # 4.36 ms of the stage-4 epoch, profiles/r03x_timeline_*)
+                            # (+ what the lane still has to do: its own accumulating convs)
+                            chain_lane = min(range(nb), key=lambda q: (
+                                lane_load.get(q, 0.0) + 55.0 * q + 35.0 * (nb - 1 - q), q != j))
+                        else:
+                            chain_lane = j
                         aux[0] += 1
                         t, Ht, Wt = ys[j]
                         for k in range(i - j - 1):
@@ -883,7 +903,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             self._engine = {}
             self._engine_ver = ver
         key = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
-               self.wino4_min_hw, self._group_on(), self._dag_eff, self.dag_aux, self.dag_no_barriers,
+               self.wino4_min_hw, self._group_on(), self._dag_eff, self.dag_aux, self.dag_no_barriers, self.dag_balance,
                tuple(sorted(self.layer_algo.items())),
                self.tile_flags, tuple(sorted(self.tile_overrides.items())))
         eng = self._engine.get(key)

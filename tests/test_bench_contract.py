@@ -62,3 +62,32 @@ def test_committed_measurement_line_has_the_contract_fields():
     assert abs(rf['achieved'] - rf['bytes_per_launch_group'] / rf['ms_per_launch_group'] / 1e6) < 1e-6 * rf['achieved']
     assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9 and rf['frac'] > 0.25
     assert r['cpu_baseline']['kind'] == 'port' and max(r['parity']['maxabs'].values()) < 1e-4
+
+
+def test_round3_bench_line_reports_the_executed_mfma_fraction():
+    """roofline.frac must be a fraction -- executed MFMA FLOPs / peak, <= 1 by
+    construction --, the direct-convolution-equivalent rate goes to its own field, traffic is a
+    number from the PMC pass of the SAME conv_algo."""
+    with open(osp.join(ROOT, 'profiles', 'r03x_bench_f32_winograd4_dag_default.json')) as f:
+        r = json.loads(f.read().strip().splitlines()[-1])
+    with open(osp.join(ROOT, 'BASELINE.json')) as f:
+        assert r['metric'] == json.load(f)['metric']
+    rf = r['roofline']
+    assert rf['bound'] == 'mfma' and rf['peak'] == 157.3 and rf['unit'] == 'TFLOP/s'
+    assert 0.0 < rf['frac'] <= 1.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    assert abs(rf['achieved'] - rf['flop_per_launch_group'] / rf['ms_per_launch_group'] / 1e9) < 1e-6 * rf['achieved']
+    assert rf['algorithmic_equiv_tflops'] > rf['achieved']
+    assert abs(rf['algorithmic_flop_per_launch_group'] - 2 * 18_466_524_160 * 64) < 1
+    assert isinstance(rf['traffic'], float) and rf['traffic_detail']['conv_algo'] == r['config']['conv_algo']
+    assert r['parity']['betas_l2'] < 1e-4 and r['parity']['vertices_maxabs'] < 1e-4
+    cb = r['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and 'median of 3' in cb['sample']
+
+
+def test_round3_bvh_line():
+    with open(osp.join(ROOT, 'profiles', 'r03z_bench_bvh.json')) as f:
+        r = json.loads(f.read().strip().splitlines()[-1])
+    assert r['unit'] == 'mesh pairs/sec' and r['config']['pairs'] == 1000
+    assert r['parity']['faces_equal'] and r['parity']['bcs_equal']
+    rf = r['roofline']
+    assert rf['bound'] == 'hbm' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
