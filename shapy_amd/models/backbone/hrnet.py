@@ -1061,11 +1061,16 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         if use_graph:
             return {'concat': self._forward_graph(lib, eng, x)}
         need = eng['ws_per_img'] * B * eng['esz']
-        if eng['ws'] is None or eng['ws'].numel() < need:
-            eng['ws'] = torch.empty(need, dtype=torch.uint8, device=x.device)
+        # one workspace per CALLER stream: forwards issued on different streams (two batches in
+        # flight, bench.py --pipeline-streams) must not share activations
+        if eng['ws'] is None:
+            eng['ws'] = {}
+        sk = torch.cuda.current_stream().cuda_stream
+        if sk not in eng['ws'] or eng['ws'][sk].numel() < need:
+            eng['ws'][sk] = torch.empty(need, dtype=torch.uint8, device=x.device)
         feat = torch.empty(B, eng['feat_dim'], dtype=torch.float32, device=x.device)
         rc = lib.shapy_hrnet_run(eng['ops'], eng['n_ops'], _lib.ptr(eng['weights']), _lib.ptr(x),
-                                 _lib.ptr(eng['ws']), eng['ws_per_img'], _lib.ptr(feat), B, H, W,
+                                 _lib.ptr(eng['ws'][sk]), eng['ws_per_img'], _lib.ptr(feat), B, H, W,
                                  int(self.multi_stream), eng['dtype'], _lib.current_stream())
         _lib.check(rc, 'shapy_hrnet_run')
         return {'concat': feat}
