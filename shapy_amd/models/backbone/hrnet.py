@@ -361,9 +361,17 @@ class _Plan:
         touch = {id(b): sorted({j for (j, _, _, _) in b.acc}) for b in used}
         mask = {id(b): sum(1 << j for j in touch[id(b)]) for b in used}
 
+        # common[b] = the ops that precede EVERY use of b
+        common = {}
+        for b in used:
+            c = -1
+            for v in touch[id(b)]:
+                c &= hb[v]
+            common[id(b)] = c
+
         def before(a, b):          # every use of a precedes every use of b
             ma = mask[id(a)]
-            return all((hb[v] & ma) == ma for v in touch[id(b)])
+            return (common[id(b)] & ma) == ma
         placed, total = [], 0
         for b in sorted(used, key=lambda b: (touch[id(b)][0], -b.size)):
             conflicts = sorted((p.off, p.size) for p in placed if not (before(p, b) or before(b, p)))
@@ -936,7 +944,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         return eng
 
     # ---- Winograd numerics guard -----------------------------------------------------------
-    def calibrate(self, x, budget=None, demote=True, log=None):
+    def calibrate(self, x, budget=None, demote=True, log=None, graph=False):
         """One-batch calibration of the Winograd layers on probe images ``x`` [B,3,H,W] (cuda).
 
         F(4x4,3x3) with the points {0, +-1, +-2, inf} multiplies by up to 8 in its transforms and
@@ -958,12 +966,12 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         lib = _lib.load()
         x = x.contiguous().float()
         B, _, H, W = x.shape
-        keep = self.multi_stream, self.group_branches
         report = None
         try:
-            self.multi_stream, self.group_branches = False, False       # one op = one launch
             for _ in range(3):
-                eng = self._compile(H, W, x.device)
+                # the product's own engine (same plan key): the pass below runs its ops one at a
+                # time on the caller's stream, whatever lanes / groups / events the plan carries
+                eng = self._compile(H, W, x.device, graph=graph)
                 layers = self._calibrate_pass(lib, eng, x)
                 worst = {}
                 for name, algo, e_rms, e_max in layers:
@@ -980,7 +988,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                     self.layer_algo[name] = to
                 report['demoted'] = dict(self.layer_algo)
         finally:
-            self.multi_stream, self.group_branches = keep
+            pass
         self.calibration_report = report
         self._calibrated_ver = self._weights_version()
         return report
@@ -1052,17 +1060,17 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         if H % 32 or W % 32:
             raise ValueError('HRNet input height/width must be multiples of 32')
         x = x.contiguous().float()
+        use_graph = self.use_graph is True or (self.use_graph == 'auto' and B <= self.graph_max_batch)
         if (self.wino_guard and self.compute_dtype == 'f32' and self.conv_algo in ('winograd', 'winograd4', 'auto')
                 and self._calibrated_ver != self._weights_version()):
             self.layer_algo = {}
-            self.calibrate(x[:min(B, 8)])            # a few images are enough to see a layer misbehave
-        use_graph = self.use_graph is True or (self.use_graph == 'auto' and B <= self.graph_max_batch)
+            self.calibrate(x[:min(B, 8)], graph=use_graph)   # a few images show a misbehaving layer
         eng = self._compile(H, W, x.device, graph=use_graph)
         if use_graph:
             return {'concat': self._forward_graph(lib, eng, x)}
         need = eng['ws_per_img'] * B * eng['esz']
-        # one workspace per CALLER stream: forwards issued on different streams (two batches in
-        # flight, bench.py --pipeline-streams) must not share activations
+        # one workspace per CALLER stream: forwards issued on different streams (several batches
+        # in flight) must not share activations
         if eng['ws'] is None:
             eng['ws'] = {}
         sk = torch.cuda.current_stream().cuda_stream

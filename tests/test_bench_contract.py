@@ -68,7 +68,7 @@ def test_round3_bench_line_reports_the_executed_mfma_fraction():
     """roofline.frac must be a fraction -- executed MFMA FLOPs / peak, <= 1 by
     construction --, the direct-convolution-equivalent rate goes to its own field, traffic is a
     number from the PMC pass of the SAME conv_algo."""
-    with open(osp.join(ROOT, 'profiles', 'r03x_bench_f32_winograd4_dag_default.json')) as f:
+    with open(osp.join(ROOT, 'profiles', 'r03z_bench_f32_default.json')) as f:
         r = json.loads(f.read().strip().splitlines()[-1])
     with open(osp.join(ROOT, 'BASELINE.json')) as f:
         assert r['metric'] == json.load(f)['metric']
