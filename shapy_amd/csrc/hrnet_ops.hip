@@ -117,6 +117,28 @@ struct Lanes {
 static Lanes g_lanes[16];
 static std::mutex g_lanes_mu;
 
+// Side stream of lane li + 1, created on first use: HIP spreads streams over a few hardware queues,
+// so streams that no plan uses (the auxiliary lanes 4..6 of the dag_aux experiment) should not exist.
+// (SHAPY_LANE_PRIO=0 turns the priorities off; +1.1..1.6 % end to end, run T of round 3) lane i + 1
+// (the branch with the smaller maps = the longer chain of latency-bound launches) gets a higher
+// stream priority than lane i.
+static int lane_stream(Lanes *L, int li, hipStream_t *out) {
+  if (!L->s[li]) {
+    static const int prio_mode = getenv("SHAPY_LANE_PRIO") ? atoi(getenv("SHAPY_LANE_PRIO")) : 1;
+    if (prio_mode) {
+      int plo = 0, phi = 0;
+      SHAPY_HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi));    // phi = highest (numerically lowest)
+      int pr = plo - (li % 3 + 1);
+      if (pr < phi) pr = phi;
+      SHAPY_HIP_TRY(hipStreamCreateWithPriority(&L->s[li], hipStreamNonBlocking, pr));
+    } else {
+      SHAPY_HIP_TRY(hipStreamCreateWithFlags(&L->s[li], hipStreamNonBlocking));
+    }
+  }
+  *out = L->s[li];
+  return SHAPY_OK;
+}
+
 static int get_lanes(Lanes **out) {
   int dev = 0;
   SHAPY_HIP_TRY(hipGetDevice(&dev));
@@ -124,20 +146,8 @@ static int get_lanes(Lanes **out) {
   std::lock_guard<std::mutex> lk(g_lanes_mu);
   Lanes &L = g_lanes[dev];
   if (!L.ready) {
-    // (SHAPY_LANE_PRIO=0 turns it off; +1.1..1.6 % end to end, run T of round 3) side lane i (the branch with the smaller maps = the longer chain
-    // of latency-bound launches) gets a higher stream priority than lane i - 1
-    static const int prio_mode = getenv("SHAPY_LANE_PRIO") ? atoi(getenv("SHAPY_LANE_PRIO")) : 1;
-    int plo = 0, phi = 0;
-    SHAPY_HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi));      // phi = highest (numerically lowest)
-    for (int i = 0; i < N_SIDE; ++i) {
-      if (prio_mode) {
-        int pr = plo - (i % 3 + 1);
-        if (pr < phi) pr = phi;
-        SHAPY_HIP_TRY(hipStreamCreateWithPriority(&L.s[i], hipStreamNonBlocking, pr));
-      } else
-        SHAPY_HIP_TRY(hipStreamCreateWithFlags(&L.s[i], hipStreamNonBlocking));
+    for (int i = 0; i < N_SIDE; ++i)
       SHAPY_HIP_TRY(hipEventCreateWithFlags(&L.join[i], hipEventDisableTiming));
-    }
     SHAPY_HIP_TRY(hipEventCreateWithFlags(&L.fork, hipEventDisableTiming));
     for (int i = 0; i < N_EVENTS; ++i)
       SHAPY_HIP_TRY(hipEventCreateWithFlags(&L.ev[i], hipEventDisableTiming));
@@ -191,15 +201,18 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
       }
       if (o.lane > 0 && o.lane <= N_SIDE) {
         const int li = o.lane - 1;
+        {
+          const int rc = lane_stream(L, li, &s);
+          if (rc) return rc;
+        }
         if (!forked[li]) {
           if (!fork_recorded) {
             SHAPY_HIP_TRY(hipEventRecord(L->fork, main));
             fork_recorded = true;
           }
-          SHAPY_HIP_TRY(hipStreamWaitEvent(L->s[li], L->fork, 0));
+          SHAPY_HIP_TRY(hipStreamWaitEvent(s, L->fork, 0));
           forked[li] = true;
         }
-        s = L->s[li];
         dirty[li] = true;
       }
     }

@@ -455,10 +455,12 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.tile_overrides = {}
         self.tile_flags = 0          # OR-ed into every conv's tile id (tuning knobs)
         #: replay the forward as one hipGraph (csrc/capi.hip) instead of ~330 launches: True,
-        #: False, or 'auto' = for batches up to graph_max_batch, where the host launch cost
-        #: exceeds the GPU time
+        #: False, or 'auto' = for batches up to graph_max_batch
         self.use_graph = 'auto'
-        self.graph_max_batch = 8
+        #: round 3: 0 = 'auto' never captures -- with the event-driven plan and lane priorities the
+        #: eager forward is faster than the replay at every batch size (B = 1: 5.5 vs 6.3 ms, B = 8:
+        #: 6.1 vs 7.4, B = 64: 12.8 vs 14.0; run AC) -- set use_graph = True to replay anyway
+        self.graph_max_batch = 0
         #: 'f32' = exact-f32 MFMA (parity path); 'f32x6' = float32 storage, products from the
         #: exact 3-way bf16 split on the bf16 matrix cores (float32-class accuracy);
         #: 'bf16' = bf16 weights/activations, f32 accumulate
