@@ -708,7 +708,10 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                                      lane=side_lane if side_lane is not None else lane,
                                      name=name + '.downsample')
                 else:
-                    idt, _, _ = conv(m.downsample[0], m.downsample[1], x, Hc, Wc, lane=lane,
+                    # event-driven plans: the projection of layer1's first Bottleneck (64 -> 256, 82 us
+                    # at HBM speed) runs beside conv1 / conv2 on lane 1; conv3 waits for its event
+                    idt, _, _ = conv(m.downsample[0], m.downsample[1], x, Hc, Wc,
+                                     lane=1 if (self._dag_eff and lane == 0 and side_lane is None) else lane,
                                      name=name + '.downsample')
             t, _, _ = conv(m.conv1, m.bn1, x, Hc, Wc, relu=True, lane=lane, name=name + '.conv1')
             t, _, _ = conv(m.conv2, m.bn2, t, Hc, Wc, relu=True, lane=lane, name=name + '.conv2')
