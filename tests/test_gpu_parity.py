@@ -664,7 +664,8 @@ def test_hrnet_event_driven_plan_equals_barrier_plan(network, B, size, graph):
             got = [bb(x)['concat'].clone() for _ in range(3)]
         torch.cuda.synchronize()
         if not graph:        # (captured plans keep the barrier form)
-            plan = [e for k, e in bb._engine.items() if k[8] is True and k[0] == size][-1]['plan']
+            plan = [e for k, e in bb._engine.items()
+                    if k[7] is False and k[8] is True and k[0] == size][-1]['plan']      # not grouped, dag
             assert sum(1 for o in plan.ops if o['sig'] >= 0) > 20
     finally:
         bb.dag, bb.multi_stream, bb.use_graph = keep
