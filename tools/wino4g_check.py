@@ -40,7 +40,7 @@ def make_desc(B, H, W, C, O, res, relu, coff=0, extra_ld=0, g=None):
     return d, dict(x=x, w=w, b=b, wu=wu, r=r, out=out)
 
 
-def run_case(lib, shapes, seed, ticket, stream):
+def run_case(lib, shapes, seed, stream):
     g = torch.Generator().manual_seed(seed)
     descs, keep = [], []
     for s in shapes:
@@ -81,7 +81,6 @@ def main():
     args = ap.parse_args()
     lib = _lib.load()
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    ticket = torch.zeros(16, dtype=torch.int32, device='cuda')
     ok = True
     if args.canary:
         cases = [
@@ -96,10 +95,10 @@ def main():
             [(40, 56, 56, 48, 48, True, True)],                                # more tasks than workgroups
         ]
         for i, c in enumerate(cases):
-            ok &= run_case(lib, c, 10 + i, ticket, stream)
-        # the same ticket block again and again (self-cleaning), twice the same group
+            ok &= run_case(lib, c, 10 + i, stream)
+        # the same group again and again
         for rep in range(3):
-            ok &= run_case(lib, cases[4], 50 + rep, ticket, stream)
+            ok &= run_case(lib, cases[4], 50 + rep, stream)
         print('CANARY', 'OK' if ok else 'FAILED')
     if args.bench:
         B = args.batch

@@ -2,7 +2,7 @@
 variant library with -DSHAPY_W4G_TIMING and prints the wall_clock64 stamps of a mid-grid workgroup
 (one multiplying wave, the staging wave) for a few groups at B = 64.
 
-    [SHAPY_W4G_STATIC=1] python tools/wino4g_timing.py       # on a GPU box
+    python tools/wino4g_timing.py       # on a GPU box
 """
 import ctypes
 import os
@@ -14,7 +14,7 @@ ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANT = '/tmp/libshapy_w4g_timing.so'
 MULT = {1: 'task start', 2: 'at barrier', 3: 'barrier passed', 4: 'epilogue start', 5: 'epilogue end'}
-STAGE = {0: 'start', 1: 'task top', 2: 'claimed', 3: 'chunk staged', 4: 'barrier passed'}
+STAGE = {0: 'start', 1: 'task top', 3: 'chunk staged', 4: 'barrier passed'}
 
 
 def main():
@@ -30,7 +30,6 @@ def main():
     lib.shapy_debug_w4g_times.restype = ctypes.c_int
     lib.shapy_debug_w4g_times.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    ticket = torch.zeros(16, dtype=torch.int32, device='cuda')
     B = 64
     groups = {'48 alone': [(B, 56, 56, 48, 48, True, True)],
               'stage3': [(B, 56, 56, 48, 48, True, True), (B, 28, 28, 96, 96, True, True),
