@@ -42,42 +42,56 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float *__restrict_
                                                         const float *__restrict__ bias,
                                                         OutT *__restrict__ out, int B, int H, int W,
                                                         int Ho, int Wo, int out_ld) {
+  // 256 threads = 2 segments of 16 consecutive output pixels (Wo % 16 == 0: a segment never leaves
+  // its row) x 8 groups of 8 output channels.  Each segment first stages its input patch
+  // (3 channels x 3 rows x 33 columns, zero padding applied) in LDS with coalesced row reads;
+  // round 2 had every thread fetch its 27 taps from global memory, 8 lanes the same address and
+  // neighbouring pixels two floats apart: load-issue-bound at 172 us for B = 64 (a 60 us job by HBM
+  // traffic).  Same taps in the same order -> bit-identical results.
   __shared__ float w[27 * 64];   // w[k][n], k = (kh*3+kw)*3 + c
+  __shared__ float patch[2][3][3][34];
   for (int i = threadIdx.x; i < 27 * 64; i += 256) {
     const int n = i & 63, k = i >> 6;
     w[i] = wgt[n * 27 + k];
   }
-  __syncthreads();
-  const int g = threadIdx.x & 7;
-  const long pix = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int seg = threadIdx.x >> 7, ts = threadIdx.x & 127;
   const long npix = (long)B * Ho * Wo;
-  if (pix >= npix) return;
-  const int wo = (int)(pix % Wo);
-  const long tq = pix / Wo;
+  const long seg_pix0 = (long)blockIdx.x * 32 + seg * 16;
+  const bool seg_live = seg_pix0 < npix;
+  const int wo0 = (int)(seg_pix0 % Wo);
+  const long tq = seg_pix0 / Wo;
   const int ho = (int)(tq % Ho);
   const int b = (int)(tq / Ho);
+  if (seg_live) {
+    const float *inb = in + (long)b * 3 * H * W;
+    for (int idx = ts; idx < 3 * 3 * 33; idx += 128) {
+      const int c = idx / 99, r = (idx % 99) / 33, j = idx % 33;
+      const int hi = ho * 2 - 1 + r, wi = wo0 * 2 - 1 + j;
+      const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      patch[seg][c][r][j] = ok ? inb[((long)c * H + hi) * W + wi] : 0.f;
+    }
+  }
+  __syncthreads();
+  if (!seg_live) return;
+  const int g = ts & 7, pl = ts >> 3;
+  const long pix = seg_pix0 + pl;
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  const float *inb = in + (long)b * 3 * H * W;
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
-    const int hi = ho * 2 - 1 + kh;
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-      const int wi = wo * 2 - 1 + kw;
-      const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float x = ok ? inb[((long)c * H + hi) * W + wi] : 0.f;
+        const float x = patch[seg][c][kh][2 * pl + kw];
         const float *wk = w + ((kh * 3 + kw) * 3 + c) * 64 + g * 8;
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = fmaf(x, wk[i], acc[i]);
       }
     }
   }
-  // the 8 channels of a thread as 16-byte stores (8 lanes = the pixel's whole 256-byte row; scalar
-  // stores wrote 4-byte pieces: 175 us for the 205 MB of B = 64, a 60 us job at HBM speed)
+  // the 8 channels of a thread as 16-byte stores (8 lanes = the pixel's whole 256-byte row)
   OutT *o = out + pix * out_ld + g * 8;
   float r[8];
 #pragma unroll
@@ -272,7 +286,8 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
         return rc;
       }
     } else if (o.type == SHAPY_OP_STEM) {
-      if (o.Cin != 3 || o.Cout != 64 || o.ksize != 3 || o.stride != 2) return SHAPY_EINVAL;
+      // (Wo % 16: the kernel's 16-pixel segments must not straddle rows; W % 32 == 0 guarantees it)
+      if (o.Cin != 3 || o.Cout != 64 || o.ksize != 3 || o.stride != 2 || o.Wo % 16) return SHAPY_EINVAL;
       const long npix = (long)B * o.Ho * o.Wo;
       // the stem's own weights stay float32 (wgt_off counts float32 elements for this op)
       const dim3 grid((unsigned)((npix + 31) / 32));
