@@ -851,6 +851,33 @@ def test_mesh_to_mesh_operator_bit_exact_vs_oracle():
     assert (e[0] == -1).all() and (e[1] == 0).all()
 
 
+def test_mesh_to_mesh_bvh_large_target_fallback_paths_vs_oracle():
+    """Targets beyond what the LBVH build keeps in LDS (SMPL-X: sorted keys as (Morton, face16) and
+    the refit's ready lists fit 128 KB up to ~21,800 / ~26,000 triangles): two bodies side by side
+    = 41,816 triangles take the build's global-memory paths (64-bit keys from L2 for the radix
+    tree, climbing refit with workgroup-scope fences, three 16,384-key sort blocks + global merge
+    stages).  Same hits as the brute-force C oracle."""
+    _need_gpu()
+    import mesh_mesh_intersect_cuda
+    from oracle import measure as om
+    from shapy_amd.utils import synthetic as syn
+    faces, meshes = syn.load_topology()
+    tris = np.ascontiguousarray(meshes[:, faces])                       # 4,F,3,3
+    shift = np.array([0.35, 0.0, 0.0], np.float32)
+    target = np.ascontiguousarray(np.concatenate([tris[[0, 1]], tris[[2, 3]] + shift], axis=1))   # 2 x 41,816
+    q = np.ascontiguousarray(np.concatenate([tris[[1, 0]][:, 3000:3040], tris[[3, 2]][:, 5000:5040] + shift],
+                                            axis=1))                    # 80 query triangles
+    mc = 96
+    f_ref, b_ref = om.mesh_to_mesh_forward(q, target, mc)
+    assert om.mesh_to_mesh_forward.last_dropped == 0 and (f_ref >= 0).sum() > 100
+    f, b = mesh_mesh_intersect_cuda.mesh_to_mesh_forward(
+        torch.from_numpy(q).cuda(), torch.from_numpy(target).cuda(), max_collisions=mc)
+    torch.cuda.synchronize()
+    assert int(mesh_mesh_intersect_cuda.mesh_to_mesh_forward.last_overflow.item()) == 0
+    assert np.array_equal(f.cpu().numpy(), f_ref)
+    assert np.array_equal(b.cpu().numpy(), b_ref)
+
+
 def test_measurements_large_batch_properties(network):
     """Config 4 at full size (1,000 meshes): size-independent properties."""
     from shapy_amd.utils import synthetic as syn
