@@ -191,6 +191,41 @@ def test_plan_orders_every_memory_hazard(hrnet, dag, group, aux):
     assert total * 4 / 1e6 < 20.0            # MB per 224x224 image: packing works (no reuse: 112 MB)
 
 
+@pytest.mark.parametrize('size', [64, 256])
+def test_event_driven_plan_at_other_input_sizes(hrnet, size):
+    """The dependency events fit their 64 slots and at most three waits per op at the sizes the
+    reference uses besides 224 (256: expose configs; 64: the smallest legal input), and the
+    executor's order still covers every hazard of the packed workspace."""
+    keep = hrnet._dag_eff, hrnet.conv_algo
+    try:
+        hrnet._dag_eff, hrnet.conv_algo = True, 'winograd4'
+        P = hrnet._build_plan(size, size)
+        waits = P.sync_plan()
+        total = P.allocate()
+    finally:
+        hrnet._dag_eff, hrnet.conv_algo = keep
+    ops = P.ops
+    assert max(len(w) for w in waits) <= 3 and max(o['sig'] for o in ops) < 64
+    reach = _executor_order(ops)
+    spans = []
+    for i, o in enumerate(ops):
+        for key, is_w in (('inb', False), ('resb', False), ('outb', True)):
+            b = o.get(key)
+            if b is not None:
+                spans.append((i, is_w, b.off, b.off + b.size, id(b)))
+    n_checked = 0
+    for x in range(len(spans)):
+        i, wi, s0, e0, bi = spans[x]
+        for y in range(x + 1, len(spans)):
+            j, wj, s1, e1, bj = spans[y]
+            if i == j or bi == bj or not (wi or wj) or s1 >= e0 or s0 >= e1:
+                continue                      # (same-buffer channel slices: the 224 test)
+            u, v = min(i, j), max(i, j)
+            assert (reach[v] >> u) & 1, (ops[u].get('name'), ops[v].get('name'))
+            n_checked += 1
+    assert n_checked > 100 and total > 0
+
+
 def test_bn_fold_matches_conv_bn_eval():
     from shapy_amd.models.backbone.hrnet import _fold
     torch.manual_seed(0)
