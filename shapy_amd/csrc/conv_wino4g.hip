@@ -37,6 +37,7 @@
 
 #include "conv_common.h"
 #include "conv_wino4.h"
+#include "conv_wino4g_sched.h"
 
 namespace shapy {
 
@@ -80,26 +81,7 @@ __device__ int g_w4g_n[2];
 
 constexpr int W4G_BAD = 0x40000000;           // >= num_records of every buffer used here
 
-// Next task of this workgroup or -1.  A task id packs (convolution g, n tile, m tile) as
-// g << 28 | n << 20 | m.  The per-XCD list of convolution g holds the flat n-major task ids
-// [T_g x / 8, T_g (x + 1) / 8), T_g = nbx * nby.  (sg, sk) = position in the schedule.
-__device__ __forceinline__ int w4g_next(const W4Group &G, int xcd, int slot, int &sg, int &sk) {
-  while (sg < G.n) {
-    const int nby = G.c[sg].nby;
-    const long T = (long)G.c[sg].nbx * nby;
-    const int lo = (int)((T * xcd) >> 3), hi = (int)((T * (xcd + 1)) >> 3);
-    const int i = G.first[sg][slot] + sk;
-    if (sk < G.count[sg][slot] && i < hi - lo) {
-      ++sk;
-      const int f = lo + i;
-      const int n = f / nby;
-      return (sg << 28) | (n << 20) | (f - n * nby);
-    }
-    ++sg;
-    sk = 0;
-  }
-  return -1;
-}
+// (task order, the packed task id and the host's schedule: conv_wino4g_sched.h)
 
 // the B-fragment addressing of one task (multiplying waves)
 struct W4Filt {
@@ -284,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4g_kernel(W4Group G) {
     W4G_STAMP(1, 0);
     const int slot = blockIdx.x >> 3;
     int sg = 0, sk = 0;
-    int cur = w4g_next(G, xcd, slot, sg, sk);
+    int cur = w4g_next_task(G, xcd, slot, sg, sk);
     if (lane == 0) mbox[0] = cur;
     wino4_lds_barrier();                       // opening barrier: the first task id is published
     int gc = 0, tk = 0;
@@ -296,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4g_kernel(W4Group G) {
     while (cur >= 0) {
       const int CC = CCn;
       W4G_STAMP(1, 1);
-      const int nxt = w4g_next(G, xcd, slot, sg, sk);
+      const int nxt = w4g_next_task(G, xcd, slot, sg, sk);
       for (int cc = 0; cc < CC; ++cc) {
         bool more = cc + 1 < CC;
         int c0n = (cc + 1) * 16;
@@ -422,32 +404,7 @@ int conv2d_wino4_group(const ConvK *ks, int n, hipStream_t s) {
   if (slots < 1) slots = 1;
   const long per_xcd = (tasks + 7) / 8;
   if (slots > per_xcd) slots = (int)per_xcd;
-  // longest-processing-time schedule for the LONGEST per-XCD list of every convolution
-  // (ceil(T / 8) tasks; an XCD whose list is one shorter clips).  Cost of a task in chunk units:
-  // its K loop + 2 for the epilogue and the hand-over (measured: epilogue 3-5 us, chunk 2.5-5 us).
-  long load[64] = {0};
-  for (int g = 0; g < n; ++g) {
-    const long T = (long)G.c[g].nbx * G.c[g].nby;
-    const int cnt = (int)((T + 7) / 8);
-    const long cost = G.c[g].Cin / 16 + 2;
-    int per[64] = {0};
-    for (int t = 0; t < cnt; ++t) {
-      int best = 0;
-      for (int q = 1; q < slots; ++q)
-        if (load[q] < load[best]) best = q;
-      load[best] += cost;
-      ++per[best];
-    }
-    int acc = 0;
-    for (int q = 0; q < 64; ++q) {
-      if (per[q] > 65535 || acc > 65535) return SHAPY_EINVAL;
-      G.count[g][q] = (unsigned short)per[q];
-      G.first[g][q] = (unsigned short)acc;
-      acc += per[q];
-    }
-  }
-  for (int g = n; g < 4; ++g)
-    for (int q = 0; q < 64; ++q) G.count[g][q] = G.first[g][q] = 0;
+  if (!w4g_make_schedule(G, slots)) return SHAPY_EINVAL;       // conv_wino4g_sched.h
   hipLaunchKernelGGL(conv_wino4g_kernel, dim3((unsigned)(8 * slots)), dim3(256), 0, s, G);
   return (int)hipGetLastError();
 }

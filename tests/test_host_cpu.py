@@ -643,3 +643,21 @@ def test_grouped_branch_levels_plan(hrnet):
 def collections_counter(it):
     import collections
     return collections.Counter(it)
+
+
+def test_w4g_schedule_native(tmp_path):
+    """The task scheduling of the persistent grouped F(4x4) kernel (host LPT schedule + the per-slot
+    task decode the kernel runs) lives in a HIP-free header: compile THAT header with g++ and replay
+    every (XCD, slot) of HRNet's level groups at B = 1 / 3 / 64 / 334 and of odd shapes -- every task
+    exactly once, on its own XCD, slots balanced (tests/native/w4g_sched_test.cpp)."""
+    import shutil
+    import subprocess
+    root = osp.dirname(osp.dirname(osp.abspath(__file__)))
+    cxx = shutil.which('g++') or shutil.which('c++')
+    if cxx is None:
+        pytest.skip('no host C++ compiler')
+    exe = str(tmp_path / 'w4g_sched_test')
+    subprocess.check_call([cxx, '-O2', '-std=c++17', '-I', osp.join(root, 'shapy_amd', 'csrc'),
+                           osp.join(root, 'tests', 'native', 'w4g_sched_test.cpp'), '-o', exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and 'W4G SCHEDULE OK' in r.stdout, r.stdout[-2000:]
