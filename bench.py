@@ -30,6 +30,9 @@ Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
   cpu_baseline  the CPU oracle ("port": torch-CPU restatement of the reference) timed on this
                 host's cores on a bounded sample of the same workload
   rccl_ranks / per_rank   (N > 1) number of RCCL ranks and each rank's own images/s
+  also          (default N = 1 run) compact sub-records of the OTHER BASELINE configurations, timed
+                after the headline's timed region: configs[0] (SMPL-X layer), configs[2]'s per-GPU
+                shard (bf16, bs 32), configs[3] (1,000 meshes), the LBVH path, the 256 x 256 crop
 """
 import argparse
 import json
@@ -63,11 +66,30 @@ def baseline_metric():
 
 def _f32_plan(net, size):
     """The backbone's float32 op list at this size: the compiled engine's own plan when the run
-    is float32, a freshly built one otherwise (the bf16 / f32x6 plans pad channels)."""
-    for key, eng in net.backbone._engine.items():
-        if key[0] == size and key[1] == size and key[3] == 'f32':
-            return eng['plan']
-    return net.backbone._build_plan(size, size)
+    is float32 (the engine of the CURRENT layer_algo: the Winograd guard may have rebuilt the plan
+    after demoting layers), a freshly built one otherwise (the bf16 / f32x6 plans pad channels)."""
+    bb = net.backbone
+    cur = tuple(sorted(getattr(bb, 'layer_algo', {}).items()))
+    best = None
+    for key, eng in bb._engine.items():
+        if key[0] == size and key[1] == size and key[3] == 'f32' and key[4] == bb.conv_algo:
+            if cur in key:
+                return eng['plan']
+            best = eng['plan']
+    return best if best is not None else bb._build_plan(size, size)
+
+
+def launches_per_forward(plan):
+    """Kernel launches of one backbone forward: every op is one launch, except that the members of a
+    launch group (ShapyOp.group = n on the first of n ops) share ONE persistent launch."""
+    n, skip = 0, 0
+    for o in plan.ops:
+        if skip:
+            skip -= 1
+            continue
+        n += 1
+        skip = max(0, o.get('group', 0) - 1)
+    return n
 
 
 def conv_flop_per_image(net, size, plan=None):
@@ -127,42 +149,48 @@ def cpu_model():
 def cpu_baseline_and_parity(x_np, out, size):
     """CPU oracle on the LAST timed batch (rank 0, after the timed region): its wall time is the
     all-cores CPU baseline at the headline batch size, its result is the parity reference.
-    A second, single-thread sample (the reference pins its pools to one thread, demo.py:432)
-    is timed on a few images."""
+    SURVEY.md 8(d): warm-up 1, median of >= 5, time.perf_counter, same inputs / weights, at the
+    headline batch AND at bs = 4, all cores and ONE thread (the reference pins its pools to one
+    thread, demo.py:432)."""
     import numpy as np
     import torch
     import __graft_entry__ as ge
     state = ge.oracle_state(0)
     cores = min(torch.get_num_threads(), 64)      # more threads only add scheduling noise here
     torch.set_num_threads(cores)
-    ge.oracle_forward(x_np[:1], state=state)                      # untimed warm-up pass
-    t0 = time.perf_counter()
-    ref = ge.oracle_forward(x_np, state=state)
-    times = [time.perf_counter() - t0]
-    # median of three: a single sample moved by 1.5x between boxes (VERDICT r2); the repeats run on
-    # a third of the batch (the oracle is linear in the batch size) to keep the default run short
     n = x_np.shape[0]
-    n3 = max(1, n // 3)
-    for _ in range(2):
-        t0 = time.perf_counter()
-        ge.oracle_forward(x_np[:n3], state=state)
-        times.append((time.perf_counter() - t0) * n / n3)
-    dt = sorted(times)[1]
+    reps = int(os.environ.get('SHAPY_CPU_BASELINE_REPS', '5'))
+
+    def timed(xs, k):
+        ts, last = [], None
+        for _ in range(k):
+            t0 = time.perf_counter()
+            last = ge.oracle_forward(xs, state=state)
+            ts.append(time.perf_counter() - t0)
+        return ts, last
+    ge.oracle_forward(x_np[:min(n, 4)], state=state)              # untimed warm-up pass
+    times, ref = timed(x_np, reps)                                # the whole batch, every sample
+    dt = float(np.median(times))
+    n4 = min(n, 4)
+    times4, _ = timed(x_np[:n4], reps)
+    dt4 = float(np.median(times4))
     torch.set_num_threads(1)
     n1 = min(n, 3)
     ge.oracle_forward(x_np[:1], state=state)
-    t0 = time.perf_counter()
-    ge.oracle_forward(x_np[:n1], state=state)
-    dt1 = time.perf_counter() - t0
+    times1, _ = timed(x_np[:n1], 3)
+    dt1 = float(np.median(times1))
     torch.set_num_threads(cores)
+    fmt = lambda ts: ', '.join(f'{t:.2f}' for t in ts)            # noqa: E731
     base = {'value': n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
             'cpu_model': cpu_model(), 'host_logical_cpus': os.cpu_count(),
             'sample': f'{n} images ({size}x{size}, one batch of {n}) through the CPU oracle '
-                      f'(torch-CPU HRNet + numpy SMPL-X + C intersection + scipy hull) in {dt:.1f} s '
-                      f'(median of 3: the whole batch once, a third of it twice, scaled; '
-                      f'samples {", ".join(f"{t:.1f}" for t in times)} s)',
+                      f'(torch-CPU HRNet + numpy SMPL-X + C intersection + scipy hull): median of '
+                      f'{reps} full-batch passes after one warm-up = {dt:.2f} s (samples {fmt(times)} s)',
+            'batch_4': {'value': n4 / dt4, 'unit': 'images/sec', 'cores': cores,
+                        'sample': f'one batch of {n4} images: median of {reps} = {dt4:.2f} s '
+                                  f'(samples {fmt(times4)} s)'},
             'single_thread': {'value': n1 / dt1, 'unit': 'images/sec', 'cores': 1,
-                              'sample': f'{n1} images (one batch) in {dt1:.1f} s with '
+                              'sample': f'{n1} images (one batch), median of 3 = {dt1:.2f} s with '
                                         'torch.set_num_threads(1) (the reference pins its pools to '
                                         '1 thread, demo.py:432)'}}
     st, rs = out['stage_02'], ref['stages'][-1]
@@ -430,14 +458,15 @@ def run_bvh(args, rank, world):
     return res
 
 
-def run_smplx(args, rank, world):
+def run_smplx(args, rank, world, net=None):
     """The SMPL-X layer alone (BASELINE configs[0] shape at --batch bodies): blend shapes,
     joint regression, pose chain, skinning, landmarks.  HBM roofline per SURVEY.md 8(d)."""
     import numpy as np
     import torch
     import __graft_entry__ as ge
     from shapy_amd.models.common.pose_utils import ContinuousRotReprDecoder
-    net, _ = ge.make_network()
+    if net is None:
+        net, _ = ge.make_network()
     B = args.batch
     g = torch.Generator().manual_seed(0)
     betas = torch.randn(B, 10, generator=g).cuda()
@@ -479,6 +508,106 @@ def run_smplx(args, rank, world):
     }
 
 
+def _compact(r):
+    """The few fields of a full bench line that an `also` sub-record keeps."""
+    c = {'metric': r['metric'], 'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'],
+         'steps': r['steps'], 'dtype': r['dtype'], 'workload': r['config']['workload'],
+         'roofline': {k: r['roofline'][k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac')}}
+    if 'parity' in r:
+        c['parity'] = r['parity']
+    if 'cpu_baseline' in r:
+        c['cpu_baseline'] = {k: r['cpu_baseline'][k] for k in ('value', 'unit', 'cores', 'kind', 'sample')}
+    return c
+
+
+def also_records(args, net, x):
+    """The OTHER BASELINE.json configurations, timed in the same process right after the headline's
+    timed region (rank 0, N = 1 only) so that the driver's default run sees them too: configs[0]
+    (SMPL-X layer, batch 4 and 64), configs[2]'s per-GPU shard (bf16, bs 32), configs[3] (1,000
+    meshes), the LBVH path of the intersection operator, and the reference's default crop size
+    (256 x 256, f32, same batch).  Each is a compact record (value, ms, roofline, parity); the full
+    lines come from `--workload ...` / `--dtype bf16 --batch 32` / `--size 256`."""
+    import copy
+    import numpy as np
+    import torch
+    out = {}
+
+    def sub(**kw):
+        a = copy.copy(args)
+        a._sub = True
+        a.steps, a.warmup = 10, 3
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+    try:
+        out['configs3_measurements_1000'] = _compact(run_measurements(sub(meshes=1000), 0, 1))
+    except Exception as e:                            # a sub-record must never cost the headline
+        out['configs3_measurements_1000'] = {'error': repr(e)}
+    for b in (4, 64):
+        try:
+            out[f'configs0_smplx_b{b}'] = _compact(run_smplx(sub(batch=b), 0, 1, net=net))
+        except Exception as e:
+            out[f'configs0_smplx_b{b}'] = {'error': repr(e)}
+    try:
+        out['lbvh_1000_pairs'] = _compact(run_bvh(sub(meshes=1000, steps=5, warmup=2), 0, 1))
+    except Exception as e:
+        out['lbvh_1000_pairs'] = {'error': repr(e)}
+    # configs[2]'s per-GPU shard (bf16 storage, bs 32) and the 256 x 256 crop on the SAME network
+    bb = net.backbone
+    keep = bb.compute_dtype
+    for tag, dtype, B, size in (('configs2_bf16_b32_per_gpu_shard', 'bf16', 32, args.size),
+                                ('f32_256x256_reference_default_crop', 'f32', args.batch, 256)):
+        try:
+            from shapy_amd.utils import synthetic as syn
+            xs = x[:B] if size == args.size else torch.from_numpy(
+                syn.synthetic_images(B, size, 100)).cuda()
+            with torch.no_grad():
+                bb.compute_dtype = 'f32'
+                ref = net(xs, None) if dtype != 'f32' else None
+                bb.compute_dtype = dtype
+                for _ in range(3):
+                    o = net(xs, None)
+                ev0, ev1 = hip_events(10)
+                idx = {'i': 0}
+                h0 = bb.register_forward_pre_hook(lambda m, a: ev0[idx['i']].record())
+                h1 = bb.register_forward_hook(lambda m, a, o_: ev1[idx['i']].record())
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(10):
+                    idx['i'] = i
+                    o = net(xs, None)
+                    o['stage_02']['betas'].cpu() if i == 9 else None
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                h0.remove(); h1.remove()
+            bms = float(np.mean([a.elapsed_time(b_) for a, b_ in zip(ev0, ev1)]))
+            if dtype == 'f32':
+                flop = executed_mfma_flop_per_image(net, size)
+                peak = F32_MFMA_PEAK_TFLOPS
+            else:
+                flop = conv_flop_per_image(net, size)
+                peak = BF16_MFMA_PEAK_TFLOPS
+            ach = flop * B / (bms * 1e-3) / 1e12
+            rec = {'metric': baseline_metric(), 'value': B * 10 / dt, 'unit': 'images/sec',
+                   'ms_per_step': dt / 10 * 1e3, 'steps': 10, 'dtype': dtype,
+                   'workload': f'HRNet-W48 + regressor + SMPL-X + measurements, {size}x{size}, bs={B}, {dtype}',
+                   'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                                'frac': ach / peak, 'ms_per_launch_group': bms}}
+            if ref is not None:
+                rec['parity'] = {
+                    'reference': 'the float32 HIP forward of the same images (bf16 error, reported '
+                                 'separately: the f32 path is the parity path)',
+                    'features_maxabs': float((o['features'].float() - ref['features']).abs().max()),
+                    'betas_maxabs': float((o['stage_02']['betas'].float() -
+                                           ref['stage_02']['betas']).abs().max())}
+            out[tag] = rec
+        except Exception as e:
+            out[tag] = {'error': repr(e)}
+        finally:
+            bb.compute_dtype = keep
+    return out
+
+
 def run_regressor(args, rank, world, local_rank):
     """Returns (json dict or None, finish): `finish(res)` adds the rank-0 CPU oracle fields
     (cpu_baseline, parity) and is called by main() AFTER the process group is torn down, so no
@@ -506,11 +635,24 @@ def run_regressor(args, rank, world, local_rank):
             net.backbone.wino4_min_hw = args.wino4_min_hw
         if args.tile_flags:
             net.backbone.tile_flags = int(args.tile_flags, 0)
+        if getattr(args, 'group_branches', None):
+            net.backbone.group_branches = {'auto': 'auto', 'on': True, 'off': False}[args.group_branches]
     B = args.batch
     # distinct synthetic images per rank (global batch = world * B), resident in HBM
     x_np = syn.synthetic_images(B, args.size, 100 + rank)
     x = torch.from_numpy(x_np).to(dev)
-    gatherer = parallel.BetasGatherer(world)
+    force_gather = bool(getattr(args, 'force_gather', False)) and world == 1 and not stub
+    if force_gather:
+        # one-GPU rehearsal of the N-rank step: a world-size-1 RCCL group, so the collective, c10d's
+        # RCCL stream and the deferred join of BetasGatherer all exist in THIS process
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+        dist.init_process_group('nccl', init_method='env://')
+    gatherer = parallel.BetasGatherer(world, force=force_gather,
+                                      mode=getattr(args, 'gather_mode', None))
     # the timed region includes the D2H of the betas (async copy into pinned host
     # memory on the compute stream; the closing synchronize covers the last one)
     betas_host = torch.empty(B, 10, dtype=torch.float32)
@@ -559,6 +701,9 @@ def run_regressor(args, rank, world, local_rank):
         dist.all_gather(allr, own)
         per_rank = [float(t.item()) for t in allr]
     assert betas.shape == (world * B, 10)
+    if force_gather:
+        assert torch.equal(betas, out['stage_02']['betas']) and gatherer.issued == args.steps + args.warmup
+        dist.destroy_process_group()
     assert torch.equal(betas_host, out['stage_02']['betas'].cpu())      # the D2H copy landed
     if world > 1:      # the gathered tensor really holds every rank's betas: own shard in place
         assert torch.equal(betas[rank * B:(rank + 1) * B], out['stage_02']['betas'])
@@ -612,7 +757,8 @@ def run_regressor(args, rank, world, local_rank):
     # HBM bytes per launch group (one backbone forward) from the committed PMC passes, gfx950
     # FETCH x2 correction applied
     traffic = pmc_traffic(B, args.size, args.dtype, algo)
-    n_launch = sum(1 for o in _f32_plan(net, args.size).ops if o['type'] != 2) if args.dtype == 'f32' else 330
+    n_launch = launches_per_forward(_f32_plan(net, args.size) if args.dtype == 'f32' else
+                                    next(iter(net.backbone._engine.values()))['plan'])
     traffic_other = None
     if traffic is None:      # no PMC pass of THIS algorithm yet: `traffic` stays null; the last
         # measured build of the same workload is quoted as context, labelled with its algorithm
@@ -653,8 +799,8 @@ def run_regressor(args, rank, world, local_rank):
                          'note': f'no rocprofv3 --pmc pass of conv_algo={algo} yet (traffic: null); '
                                  'last measured build of the same workload, for context only',
                          'other_build': traffic_other},
-                     'peak_sustained_measured': {'f32': 141.0, 'bf16': 1410.0,
-                                                 'f32x6': 1410.0 / 6.0}[args.dtype],
+                     'peak_microbenchmark': {'f32': 155.0, 'bf16': 2495.0,
+                                             'f32x6': 2495.0 / 6.0}[args.dtype],   # MI355X_MICROARCH.md
                      'kernel': kernel + f', {n_launch} launches per backbone forward',
                      'flop_per_launch_group': exec_img * B,
                      'ms_per_launch_group': backbone_ms,
@@ -668,8 +814,16 @@ def run_regressor(args, rank, world, local_rank):
     if world > 1:
         res['rccl_ranks'] = world
         res['per_rank'] = {'images_per_sec': per_rank,
-                           'allgather': {'issued': gatherer.issued,
+                           'allgather': {'issued': gatherer.issued, 'mode': gatherer.mode,
                                          'joined_by_next_step': gatherer.deferred_waits}}
+    if force_gather:
+        res['rccl_ranks'] = 1
+        res['force_gather'] = {'mode': gatherer.mode, 'issued': gatherer.issued,
+                               'joined_by_next_step': gatherer.deferred_waits,
+                               'note': 'world-size-1 RCCL group: the all_gather, the RCCL stream and '
+                                       'the deferred join of the N-rank step on ONE GPU'}
+    if world == 1 and not getattr(args, 'no_also', False) and not getattr(args, '_sub', False):
+        res['also'] = also_records(args, net, x)
 
     def finish(res):                                 # rank 0 only; after destroy_process_group()
         if not args.no_cpu_baseline:
@@ -698,7 +852,8 @@ def main():
                     help='skip the CPU oracle (cpu_baseline and parity fields)')
     ap.add_argument('--single-stream', action='store_true')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
-                    help='replay the backbone as one hipGraph (auto: batches <= 8)')
+                    help='replay the backbone as one hipGraph (auto: never since round 3 -- the eager '
+                         'event-driven forward is faster at every batch size; on: always)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f32x6', 'bf16'],
                     help='f32 = BASELINE configs[1] (headline) on the f32 matrix-core path; '
                          'f32x6 = same float32 tensors, products from the exact 3-way bf16 split '
@@ -714,7 +869,19 @@ def main():
                          'the line it prints carries "stub": true')
     ap.add_argument('--wino4-min-hw', type=int, default=0,
                     help='--algo winograd4: smallest map side that takes F(4x4,3x3) (default: the '
-                         'backbone\'s own, 28)')
+                         'backbone\'s own, 7)')
+    ap.add_argument('--force-gather', action='store_true',
+                    help='N = 1 only: create a world-size-1 RCCL group and take BetasGatherer\'s '
+                         'collective path (rehearsal of the N-rank step on one GPU; the line says '
+                         '"rccl_ranks": 1)')
+    ap.add_argument('--gather-mode', default=None, choices=['work', 'side'],
+                    help='BetasGatherer issue mode (shapy_amd/parallel.py; default: work)')
+    ap.add_argument('--group-branches', default=None, choices=['auto', 'on', 'off'],
+                    help='persistent grouped F(4x4) launches per depth level of a module '
+                         '(HighResolutionNet.group_branches)')
+    ap.add_argument('--no-also', action='store_true',
+                    help='skip the `also` sub-records (the other BASELINE configurations, timed after '
+                         'the headline\'s timed region in the default N = 1 run)')
     args = ap.parse_args()
 
     STUB['on'] = bool(args.cpu_stub)

@@ -384,14 +384,16 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
       return conv2d_wino4(k, s);
     }
     if (d.dtype != SHAPY_DTYPE_F32 || k.Cout % 48) return SHAPY_EINVAL;
-    // tensors beyond the kernel's 1 GiB offset scheme (B > 334 at 224x224): the direct kernel on
+    // tensors beyond the kernel's 1 GiB offset scheme (B > 334 at 224x224) or with rows that are
+    // not 16-byte aligned: the direct kernel on
     // the untransformed weights, which every layer carries -- slower, same convolution
     k.wgt2 = nullptr;
     static bool warned = false;        // once per process: a 1.7x per-layer perf cliff must not be silent
     if (!warned) {
       warned = true;
-      fprintf(stderr, "shapy: F(4x4) Winograd layer %dx%d %d->%d at M=%d exceeds the kernel's 1 GiB "
-                      "addressing; this and larger layers run the direct kernel (slower, same result)\n",
+      fprintf(stderr, "shapy: F(4x4) Winograd layer %dx%d %d->%d at M=%d is outside the kernel's limits "
+                      "(1 GiB addressing, 16-byte-aligned rows); such layers run the direct kernel "
+                      "(slower, same result)\n",
               k.Hi, k.Wi, k.Cin, k.Cout, k.M);
     }
   }

@@ -42,16 +42,33 @@ __device__ __forceinline__ void wino4_lds_barrier() {
 }
 
 
-// Epilogue of a multiplying wave (both F(4x4) kernels): output transform A^T M A in the registers
-// of the lane that holds the MFMA results (lane = channel `col`, tiles m_blk + 4 g4 + r, 16 pixels
-// each), bias + residual + ReLU, 4-byte stores (16 lanes = 64 contiguous bytes).  Residual loads
-// and stores are buffer instructions: per-lane part of the address = the tile's first pixel, pixel
-// offset inside the tile = scalar offset; pixels outside the image (partial edge tiles) and dead
-// tiles get an out-of-range offset, which drops the access.
-// One tile row's residual is in flight ahead of the one being transformed.  (Three rows ahead --
-// 48 registers, the dead filter ring -- was measured SLOWER: 55 / 45 / 48 us against 51 / 40 / 41 us
-// on the 48 / 96 / 192-channel classes, run H of round 3; the residual loads are not what the
-// epilogue waits for, a layer without residual takes the same time.)
+// one application of A^T (4 x 6) to a 6-vector of 4 channels
+__device__ __forceinline__ void wino4_at4(const f32x4 (&m)[6], f32x4 (&o)[4]) {
+  const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2];
+  const f32x4 s34 = m[3] + m[4], d34 = m[3] - m[4];
+  o[0] = (m[0] + s12) + s34;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[1][k] = fmaf(2.f, d34[k], d12[k]);
+    o[2][k] = fmaf(4.f, s34[k], s12[k]);
+    o[3][k] = fmaf(8.f, d34[k], d12[k]) + m[5][k];
+  }
+}
+
+// Epilogue of a multiplying wave (both F(4x4) kernels).  The MFMAs run with the FILTER fragment as
+// the A operand and the V fragment as B, so the C layout is D[channel 4 g + r][tile l15]: a lane
+// holds ONE tile and FOUR CONSECUTIVE output channels of it in every accumulator -- the output
+// transform A^T M A runs on float4s in the registers of the lane that holds the MFMA results, and
+// the residual loads / stores are 16 bytes per lane (4 lanes = the wave's 64-byte channel segment
+// of a pixel): 16 + 16 vector-memory instructions per wave instead of 64 + 64.  (Round 3's layout
+// -- tiles along the C rows, one channel per lane, 4-byte accesses -- made the epilogue the
+// longest phase of a task: 10-16 us next to 3 x 5 us of multiplies on the 48-channel class,
+// profiles/r03k_w4g_phase_stamps.txt; a store tail is bound by the number of store INSTRUCTIONS,
+// not by bytes.)  Products and summation order are unchanged: bit-identical outputs.
+// Residual loads and stores are buffer instructions: per-lane part of the address = the tile's
+// first pixel + the channel group, pixel offset inside the tile = scalar offset; pixels outside the
+// image (partial edge tiles) and dead tiles get an out-of-range offset, which drops the access.
+// The residual of one pixel column (4 pixels) is in flight ahead of the one being transformed.
 struct Wino4Epi {
   int dbg;                     // tuning builds (-DSHAPY_W4G_TIMING): 1 no stores, 2 no residual loads
   void *out;
@@ -61,74 +78,70 @@ struct Wino4Epi {
   int H, W, tiles, out_ld, out_coff, res_ld, res_coff, relu;
 };
 
-__device__ __forceinline__ void wino4_epilogue(const Wino4Epi &e, const f32x4 (&acc)[36], int m_blk,
-                                               int col, int g4) {
+// tile: the lane's tile (m_blk + l15); col4: its first output channel (n0 + 4 g4)
+__device__ __forceinline__ void wino4_epilogue(const Wino4Epi &e, const f32x4 (&acc)[36], int tile,
+                                               int col4) {
   constexpr int BAD = 0x40000000;
   const int H = e.H, W = e.W;
   const int TW = (W + 3) >> 2, TH = (H + 3) >> 2;
-  const float bias = e.bias ? e.bias[col] : 0.f;
+  f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (e.bias) bias = f32x4{e.bias[col4], e.bias[col4 + 1], e.bias[col4 + 2], e.bias[col4 + 3]};
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, BAD, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void *>(e.res ? e.res : e.in), 0, BAD, 0x00020000);
   const bool has_res = e.res != nullptr;
   const int out_ld = e.out_ld, res_ld = e.res_ld;
-  int obase[4], rbase[4], nrow[4], ncol[4];
+  const bool live = tile < e.tiles;
+  const int tt = live ? tile : 0;
+  const int tx = tt % TW;
+  const int tq = tt / TW;
+  const int ty = tq % TH;
+  const int b = tq / TH;
+  const int pix0 = (b * H + 4 * ty) * W + 4 * tx;
+  const int obase = live ? (pix0 * out_ld + e.out_coff + col4) * 4 : BAD;
+  const int rbase = (live & has_res) ? (pix0 * res_ld + e.res_coff + col4) * 4 : BAD;
+  const int nrow = H - 4 * ty;      // >= 4 for a full tile
+  const int ncol = W - 4 * tx;
+  const float relu_lo = e.relu ? 0.f : -__builtin_inff();
+  f32x4 resv[2][4];
+  auto rload = [&](int bb, f32x4 (&rv)[4]) {       // pixel column bb of the tile: 4 pixels
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int tile = m_blk + 4 * g4 + r;
-    const bool live = tile < e.tiles;
-    const int tt = live ? tile : 0;
-    const int tx = tt % TW;
-    const int tq = tt / TW;
-    const int ty = tq % TH;
-    const int b = tq / TH;
-    const int pix0 = (b * H + 4 * ty) * W + 4 * tx;
-    obase[r] = live ? (pix0 * out_ld + e.out_coff + col) * 4 : BAD;
-    rbase[r] = (live & has_res) ? (pix0 * res_ld + e.res_coff + col) * 4 : BAD;
-    nrow[r] = H - 4 * ty;           // >= 4 for a full tile
-    ncol[r] = W - 4 * tx;
-  }
-  float resv[2][16];
-  auto rload = [&](int r, float (&rv)[16]) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        bool ok = (a < nrow[r]) & (bb < ncol[r]);
-#ifdef SHAPY_W4G_TIMING
-        ok &= !(e.dbg & 2);
+    for (int a = 0; a < 4; ++a) {
+      bool ok = (a < nrow) & (bb < ncol);
+#if defined(SHAPY_W4G_TIMING) || defined(SHAPY_WINO_TIMING)
+      ok &= !(e.dbg & 2);
 #endif
-        rv[4 * a + bb] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-            rs_res, ok ? rbase[r] : BAD, (a * W + bb) * res_ld * 4, 0));
-      }
+      rv[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rs_res, ok ? rbase : BAD, (a * W + bb) * res_ld * 4, 0));
+    }
   };
   rload(0, resv[0]);
+  f32x4 s[6][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (r + 1 < 4) rload(r + 1, resv[(r + 1) & 1]);
-    float s[6][4];
+  for (int i = 0; i < 6; ++i) {
+    const f32x4 m[6] = {acc[6 * i + 0], acc[6 * i + 1], acc[6 * i + 2],
+                        acc[6 * i + 3], acc[6 * i + 4], acc[6 * i + 5]};
+    wino4_at4(m, s[i]);                                           // M A   (along x)
+  }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const float m[6] = {acc[6 * i + 0][r], acc[6 * i + 1][r], acc[6 * i + 2][r],
-                          acc[6 * i + 3][r], acc[6 * i + 4][r], acc[6 * i + 5][r]};
-      wino4_at(m, s[i]);                                          // M A   (along x)
-    }
+  for (int bb = 0; bb < 4; ++bb) {
+    if (bb + 1 < 4) rload(bb + 1, resv[(bb + 1) & 1]);
+    const f32x4 colv[6] = {s[0][bb], s[1][bb], s[2][bb], s[3][bb], s[4][bb], s[5][bb]};
+    f32x4 y[4];
+    wino4_at4(colv, y);                                           // A^T (M A)   (along y)
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-      const float colv[6] = {s[0][bb], s[1][bb], s[2][bb], s[3][bb], s[4][bb], s[5][bb]};
-      float y[4];
-      wino4_at(colv, y);                                          // A^T (M A)   (along y)
+    for (int a = 0; a < 4; ++a) {
+      bool ok = (a < nrow) & (bb < ncol);
+      f32x4 v = (y[a] + bias) + resv[bb & 1][a];
+      // ReLU without a branch per store and without hipcc's canonicalising second v_max:
+      // max(v, 0) or max(v, -inf)
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        bool ok = (a < nrow[r]) & (bb < ncol[r]);
-        float v = (y[a] + bias) + resv[r & 1][4 * a + bb];
-        if (e.relu) v = fmaxf(v, 0.f);
-#ifdef SHAPY_W4G_TIMING
-        if (e.dbg & 1) ok &= v == 12345.678f;
+      for (int k = 0; k < 4; ++k) asm("v_max_f32 %0, %1, %2" : "=v"(v[k]) : "v"(v[k]), "s"(relu_lo));
+#if defined(SHAPY_W4G_TIMING) || defined(SHAPY_WINO_TIMING)
+      if (e.dbg & 1) ok &= v[0] == 12345.678f;
 #endif
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, ok ? obase[r] : BAD,
-                                              (a * W + bb) * out_ld * 4, 0);
-      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, ok ? obase : BAD,
+                                             (a * W + bb) * out_ld * 4, 0);
     }
   }
 }

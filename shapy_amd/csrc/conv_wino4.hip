@@ -13,28 +13,29 @@
 // GEMM view: 36 independent GEMMs (Winograd position p = 6 i + j), [tiles x Cin] x [Cin x Cout].
 // One 256-thread workgroup = 16 consecutive tiles (4x4 output pixels each, row-major over
 // (b, ty, tx)) x N = 48 or 64 output channels:
-//   * staging, all four waves: thread (tile, channel) loads the 36 pixels of its patch as scalars
-//     (16 consecutive lanes = 64 contiguous bytes; out-of-image taps zeroed by the buffer bounds
-//     check), applies B^T d B entirely in registers -- no cross-lane exchange -- and writes
-//     V[p][tile][16 ch] to LDS (36 KB per 16-channel chunk; 16-byte slots XOR-swizzled by the
-//     tile so that the fragment reads are conflict-free; a wave's 4-byte writes of one position
-//     cover 256 contiguous bytes).  Two V buffers, one barrier per chunk; the next chunk's patch
-//     is in flight in registers while this one is multiplied.
-//   * multiply, wave w < N/16: ALL 36 positions of ONE 16-channel tile (144 accumulator
-//     registers).  A fragments from LDS (one ds_read_b128 = the k-operands of 4 MFMAs), B
-//     fragments straight from the transformed filters in global memory, layout
-//     [p][Cin/16][Cout][16] (1 KB contiguous per wave load), a ring of WINO4_RING positions ahead.
-//     Because a wave owns every position of its (tile, channel) outputs, the output transform
-//     A^T M A happens in registers: no accumulator exchange through LDS (conv_wino.hip spends
-//     53 KB of LDS and two barriers on it).
-//   * epilogue: per lane 4 tiles x 16 pixels of one channel: bias, residual, ReLU, 4-byte
-//     stores (16 lanes = 64 contiguous bytes; the N/16 waves of the workgroup cover the pixel's
-//     whole 192- / 256-byte row).
-// With N = 48 the fourth wave only stages: the register budget (256 per lane) allows two waves
-// per SIMD either way, so the idle slot costs no occupancy.
+//   * staging, ONE wave (wave 3): lane (tile, 4 channels) loads the 6 x 6 patch of its tile as 36
+//     16-byte loads (out-of-image taps zeroed by the buffer bounds check), applies B^T d B entirely
+//     in registers -- no cross-lane exchange -- and writes V[p][tile][16 ch] to LDS (36 KB per
+//     16-channel chunk; 16-byte slots XOR-swizzled by the tile so that the fragment reads are
+//     conflict-free).  Two V buffers, one barrier per chunk; the next chunk's patch is in flight
+//     in registers while this one is multiplied.
+//   * multiply, waves 0..2: ALL 36 positions of ONE 16-channel tile (144 accumulator registers).
+//     V fragments from LDS (one ds_read_b128 = the k-operands of 4 MFMAs), filter fragments straight
+//     from the transformed filters in global memory, layout [p][Cin/16][Cout][16] (1 KB contiguous
+//     per wave load), a ring of WINO4_RING positions ahead.  The FILTER fragment is the MFMA's A
+//     operand and the V fragment its B operand, so the accumulators hold D[channel][tile]: a lane
+//     owns one tile and four consecutive output channels.  Because a wave owns every position of
+//     its (tile, channel) outputs, the output transform A^T M A happens in registers: no
+//     accumulator exchange through LDS (conv_wino.hip spends 53 KB of LDS and two barriers on it).
+//   * epilogue (conv_wino4.h): per lane 16 pixels x 4 channels: bias, residual, ReLU, 16-byte
+//     stores (4 lanes = the wave's 64 contiguous bytes of a pixel; the 3 waves of the workgroup
+//     cover the pixel's whole 192-byte row).
+// The fourth wave only stages: the register budget (256 per lane) allows two waves per SIMD either
+// way, so the slot costs no occupancy.
 #include <stdlib.h>
 
 #include "conv_common.h"
+#include "conv_wino4.h"
 
 namespace shapy {
 
@@ -47,42 +48,6 @@ namespace shapy {
 #else
 #define W4_DBG(bit) false
 #endif
-
-#ifndef WINO4_RING
-#define WINO4_RING 12         // B-fragment positions in flight per multiplying wave (divides 36)
-#endif
-
-// one application of B^T (6 x 6) to a 6-vector (of 4 channels)
-__device__ __forceinline__ void wino4_bt(const f32x4 (&d)[6], f32x4 (&o)[6]) {
-  const f32x4 a = d[4] - 4.f * d[2];
-  const f32x4 b = d[3] - 4.f * d[1];
-  const f32x4 c = d[4] - d[2];
-  const f32x4 e = d[3] - d[1];
-  o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-  o[1] = a + b;
-  o[2] = a - b;
-  o[3] = c + 2.f * e;
-  o[4] = c - 2.f * e;
-  o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
-}
-
-// one application of A^T (4 x 6) to a 6-vector
-__device__ __forceinline__ void wino4_at(const float (&m)[6], float (&o)[4]) {
-  const float s12 = m[1] + m[2], d12 = m[1] - m[2];
-  const float s34 = m[3] + m[4], d34 = m[3] - m[4];
-  o[0] = (m[0] + s12) + s34;
-  o[1] = fmaf(2.f, d34, d12);
-  o[2] = fmaf(4.f, s34, s12);
-  o[3] = fmaf(8.f, d34, d12) + m[5];
-}
-
-// Workgroup barrier WITHOUT the fence of __syncthreads(): only LDS traffic is ordered across it
-// (the staging wave's ds_writes, the multiplying waves' ds_reads).  The fence would also drain
-// vmcnt, i.e. make every wave wait for its prefetched global loads (filter ring, next patch) at
-// every chunk boundary.
-__device__ __forceinline__ void wino4_lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // 256 threads = three multiplying waves (16 output channels each, N = 48 per workgroup) + one
 // staging wave.  KC > 0: the layer has exactly KC chunks (Cin = 16 KC) and the multiplying waves'
@@ -248,10 +213,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         if (W4_DBG(4) && kk > 0) break;
+        // A operand = filter fragment, B operand = V fragment: D[channel 4 g + r][tile l15]
+        // (conv_wino4.h: the epilogue wants four consecutive channels of one tile per lane)
         acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-            __uint_as_float(af[cur][0][kk]), __uint_as_float(bring[pp % R][kk]), acc[pp], 0, 0, 0);
+            __uint_as_float(bring[pp % R][kk]), __uint_as_float(af[cur][0][kk]), acc[pp], 0, 0, 0);
         acc[pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-            __uint_as_float(af[cur][1][kk]), __uint_as_float(bring[(pp + 1) % R][kk]), acc[pp + 1],
+            __uint_as_float(bring[(pp + 1) % R][kk]), __uint_as_float(af[cur][1][kk]), acc[pp + 1],
             0, 0, 0);
       }
       // refill the two ring slots just consumed, R positions ahead (pinned here: the compiler
@@ -275,79 +242,28 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
   }
   wino4_lds_barrier();                       // barrier #CC: the staging wave's closing one
 
-  // ---- epilogue: output transform in registers, bias + residual + ReLU, store ----
-  // Per lane: channel `col`, tiles 4 g + r (MFMA C layout), 16 pixels each.  Residual loads and
-  // stores are buffer instructions: per-lane part of the address = the tile's first pixel (one
-  // register per tile), pixel offset inside the tile = scalar offset; pixels outside the image
-  // (partial edge tiles) and dead tiles get the out-of-range offset, which drops the access.
-  const int col = n0 + l15;
-  const float bias = p.bias ? p.bias[col] : 0.f;
-  const __amdgpu_buffer_rsrc_t rs_out =
-      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, BAD, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void *>(p.res ? p.res : p.in), 0, BAD, 0x00020000);
-  const bool has_res = p.res != nullptr;
-  int obase[4], rbase[4], nrow[4], ncol[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int tile = m_blk + 4 * g + r;
-    const bool live = tile < T;
-    const int tt = live ? tile : 0;
-    const int tx = tt % TW;
-    const int tq = tt / TW;
-    const int ty = tq % TH;
-    const int b = tq / TH;
-    const int pix0 = (b * H + 4 * ty) * W + 4 * tx;
-    obase[r] = live ? (pix0 * p.out_ld + p.out_coff + col) * 4 : BAD;
-    rbase[r] = (live & has_res) ? (pix0 * p.res_ld + p.res_coff + col) * 4 : BAD;
-    nrow[r] = H - 4 * ty;           // >= 4 for a full tile
-    ncol[r] = W - 4 * tx;
-  }
-  float resv[2][16];
-  auto rload = [&](int r, float (&rv)[16]) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        const bool ok = (a < nrow[r]) & (bb < ncol[r]) & !W4_DBG(2);
-        rv[4 * a + bb] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-            rs_res, ok ? rbase[r] : BAD, (a * W + bb) * p.res_ld * 4, 0));
-      }
-  };
-  rload(0, resv[0]);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (r + 1 < 4) rload(r + 1, resv[(r + 1) & 1]);
-    float s[6][4];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const float m[6] = {acc[6 * i + 0][r], acc[6 * i + 1][r], acc[6 * i + 2][r],
-                          acc[6 * i + 3][r], acc[6 * i + 4][r], acc[6 * i + 5][r]};
-      wino4_at(m, s[i]);                                          // M A   (along x)
-    }
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-      const float colv[6] = {s[0][bb], s[1][bb], s[2][bb], s[3][bb], s[4][bb], s[5][bb]};
-      float y[4];
-      wino4_at(colv, y);                                          // A^T (M A)   (along y)
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        bool ok = (a < nrow[r]) & (bb < ncol[r]);
-        float v = (y[a] + bias) + resv[r & 1][4 * a + bb];
-        if (W4_DBG(1)) ok &= v == 12345.678f;
-        if (p.relu) v = fmaxf(v, 0.f);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, ok ? obase[r] : BAD,
-                                              (a * W + bb) * p.out_ld * 4, 0);
-      }
-    }
-  }
+  // ---- epilogue: output transform in registers, bias + residual + ReLU, 16-byte stores ----
+  // (conv_wino4.h; per lane: tile m_blk + l15, channels n0 + 4 g .. + 3)
+  Wino4Epi e;
+  e.dbg = 0;
+#ifdef SHAPY_WINO_TIMING
+  e.dbg = p.dbg & 3;
+#endif
+  e.out = p.out; e.res = p.res; e.in = p.in; e.bias = p.bias;
+  e.H = H; e.W = W; e.tiles = T; e.out_ld = p.out_ld; e.out_coff = p.out_coff;
+  e.res_ld = p.res_ld; e.res_coff = p.res_coff; e.relu = p.relu;
+  wino4_epilogue(e, acc, m_blk + l15, n0 + 4 * g);
 }
 
 // The kernel marks invalid accesses with the byte offset 0x40000000: every tensor it touches has
 // to stay below 1 GiB (B <= 334 for HRNet's 256-channel 56x56 map).
 bool conv_wino4_fits(const ConvK &k) {
   const unsigned long long lim = 0x40000000ull;
-  return k.Cout % 48 == 0 && k.in_bytes <= lim && 4ull * k.M * k.out_ld <= lim &&
+  // 16-byte residual loads / stores of the epilogue: k.vec4 (conv_prepare) = rows and channel
+  // offsets in multiples of 4 floats, 16-byte-aligned tensors -- every HRNet tensor; anything else
+  // takes another kernel
+  const bool al = k.vec4 != 0;
+  return al && k.Cout % 48 == 0 && k.in_bytes <= lim && 4ull * k.M * k.out_ld <= lim &&
          (!k.res || 4ull * k.M * k.res_ld <= lim) && 144ull * k.Cin * k.Cout < 0x7fffffffull;
 }
 

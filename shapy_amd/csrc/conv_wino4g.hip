@@ -156,9 +156,9 @@ __device__ __forceinline__ int w4g_task(const W4Group &G, const int task, int &g
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-            __uint_as_float(af[cur][0][kk]), __uint_as_float(bring[pp % R][kk]), acc[pp], 0, 0, 0);
+            __uint_as_float(bring[pp % R][kk]), __uint_as_float(af[cur][0][kk]), acc[pp], 0, 0, 0);
         acc[pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-            __uint_as_float(af[cur][1][kk]), __uint_as_float(bring[(pp + 1) % R][kk]), acc[pp + 1],
+            __uint_as_float(bring[(pp + 1) % R][kk]), __uint_as_float(af[cur][1][kk]), acc[pp + 1],
             0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -199,7 +199,7 @@ __device__ __forceinline__ int w4g_task(const W4Group &G, const int task, int &g
   e.out = c.out; e.res = c.res; e.in = c.in; e.bias = c.bias;
   e.H = c.Hi; e.W = c.Wi; e.tiles = c.tiles; e.out_ld = c.out_ld; e.out_coff = c.out_coff;
   e.res_ld = c.res_ld; e.res_coff = c.res_coff; e.relu = c.relu;
-  wino4_epilogue(e, acc, (task_e & 0xfffff) * 16, ((task_e >> 20) & 0xff) * 48 + 16 * wave + l15, g4);
+  wino4_epilogue(e, acc, (task_e & 0xfffff) * 16 + l15, ((task_e >> 20) & 0xff) * 48 + 16 * wave + 4 * g4);
   W4G_STAMP(0, 5);
   return nxt;
 }

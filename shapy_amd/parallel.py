@@ -4,8 +4,8 @@ Images are independent, BatchNorm is in eval mode and the weights (418 MB) and S
 buffers (65 MB) are replicated, so the forward pass needs NO exchange: every rank (one
 process per GPU) runs a contiguous shard of the batch.  The only collective is the
 all-gather of the predicted betas ([B_local, 10] float32 = 1,280 B per rank at bs=256/8)
-at the end of a step -- latency-bound, so it is issued as ONE RCCL all_gather on a side
-stream and joined into the compute stream only when the NEXT step issues its own gather
+at the end of a step -- latency-bound, so it is issued as ONE asynchronous RCCL all_gather and
+joined into the compute stream only when the NEXT step issues its own gather
 (``BetasGatherer``): it overlaps the next batch's backbone.
 
 The reference has no data-parallel inference at all (rank > 0 returns immediately in its
@@ -34,7 +34,7 @@ def init_distributed(backend='nccl'):
 
 
 class BetasGatherer:
-    """all_gather of equally sized per-rank tensors on a side stream, DEFERRED: the current
+    """all_gather of equally sized per-rank tensors, asynchronous and DEFERRED: the current
     stream does not wait for the collective when it is issued, so the (latency-bound) RCCL
     call overlaps whatever the caller enqueues next -- in ``bench.py`` the backbone of the
     next batch.
@@ -48,12 +48,26 @@ class BetasGatherer:
     ``gather(local)`` = issue + wait for callers that need the result right away.  On CPU
     tensors (gloo) the collective is synchronous and every form returns a finished tensor."""
 
-    def __init__(self, world=None, group=None):
+    def __init__(self, world=None, group=None, force=False, mode=None):
+        """force: take the collective path even for ONE rank (bench.py --force-gather: a world-size-1
+        RCCL group exercises the stream / event structure of the N-rank path on a single GPU).
+        mode: 'work' (default) = the collective is issued from the CALLER's stream with
+        async_op=True -- c10d runs it on its own RCCL stream behind an event of the caller's stream,
+        and the Work handle is joined (a stream-side wait, not a host wait) at the next call;
+        'side' = rounds 1-3: a private side stream around a blocking call.  Both defer the join by
+        one step; 'work' needs no stream of our own (HIP multiplexes a process's streams onto a few
+        hardware queues: every extra stream costs the four-lane backbone).
+        SHAPY_GATHER_MODE overrides the default."""
+        import os
         self.group = group
         self.world = world if world is not None else (
             dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.force = bool(force)
+        self.mode = mode or os.environ.get('SHAPY_GATHER_MODE', 'work')
+        if self.mode not in ('work', 'side'):
+            raise ValueError(f'unknown gather mode {self.mode!r}')
         self._stream = None
-        self._pending = None          # (out, event) of the gather still in flight
+        self._pending = None          # (out, event | Work | None) of the gather still in flight
         self.issued = 0
         self.deferred_waits = 0       # waits that were served by a LATER call (the overlap)
 
@@ -61,14 +75,18 @@ class BetasGatherer:
         """Makes the current stream wait for the gather in flight (if any); returns its result."""
         if self._pending is None:
             return None
-        out, ev = self._pending
+        out, h = self._pending[:2]
         self._pending = None
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+        if h is None:
+            pass
+        elif isinstance(h, torch.cuda.Event):
+            torch.cuda.current_stream().wait_event(h)
+        else:
+            h.wait()                  # c10d Work: the CURRENT STREAM waits for the RCCL stream
         return out
 
     def __call__(self, local):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return local
         if self._pending is not None:
             self.deferred_waits += 1
@@ -76,7 +94,10 @@ class BetasGatherer:
         local = local.contiguous()
         out = local.new_empty((self.world * local.shape[0],) + tuple(local.shape[1:]))
         self.issued += 1
-        if local.is_cuda:
+        if local.is_cuda and self.mode == 'work':
+            work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
+            self._pending = (out, work, local)       # `local` stays referenced until the join
+        elif local.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
             self._stream.wait_stream(torch.cuda.current_stream())    # `local` is produced there

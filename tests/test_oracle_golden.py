@@ -123,6 +123,37 @@ def test_hrnet_oracle_matches_reference(golden_dir, hrnet_sd, tag, b, s):
     assert np.abs(out - g[tag]).max() < 2e-5
 
 
+def test_oracle_matches_reference_at_256(golden_dir, hrnet_sd, synth_smplx):
+    """The reference's DEFAULT crop size (config/datasets_defaults.py:30), the size demo.py feeds the
+    network: oracle backbone + head against the real reference at 2 x 256 x 256
+    (tests/golden/make_golden_256.py)."""
+    g = load(golden_dir, 'hrnet_golden_256.npz')
+    r = load(golden_dir, 'regressor_golden_256.npz')
+    x = torch.from_numpy(syn.synthetic_images(2, 256, 0))
+    with torch.no_grad():
+        feat = hrnet_torch.hrnet_forward(hrnet_sd, x, prefix='backbone.').numpy()
+    assert np.abs(feat - g['b2_256']).max() < 2e-5
+    assert np.array_equal(g['b2_256'], r['features'])
+    w = syn.synthetic_state_dict(_REGRESSOR_SPEC, 0)
+    layers = [(w[_REGRESSOR_SPEC[2 * i][0]], w[_REGRESSOR_SPEC[2 * i + 1][0]]) for i in range(3)]
+    out = body_np.regressor_head(feat, layers, synth_smplx)
+    last = out['stages'][-1]
+    assert np.abs(last['betas'] - r['stage2_betas']).max() < 1e-5
+    assert np.abs(last['joints'] - r['joints']).max() < 5e-5
+    assert np.abs(last['vertices'][:, ::SUB] - r['vertices_sub']).max() < 5e-5
+    m = measure.body_measurements(last['v_shaped'][:, synth_smplx['f']], LM)
+    for k in ('mass', 'height', 'chest', 'waist', 'hips'):
+        np.testing.assert_allclose(m[k], r['meas_' + k], rtol=1e-4, atol=1e-4, err_msg=k)
+
+
+_REGRESSOR_SPEC = [('regressor.module.layer_000.0.weight', (1024, 2193)),
+                   ('regressor.module.layer_000.0.bias', (1024,)),
+                   ('regressor.module.layer_001.0.weight', (1024, 1024)),
+                   ('regressor.module.layer_001.0.bias', (1024,)),
+                   ('regressor.module.output_layer.weight', (145, 1024)),
+                   ('regressor.module.output_layer.bias', (145,))]
+
+
 def test_full_regressor_oracle_matches_reference(golden_dir, hrnet_sd, synth_smplx):
     g = load(golden_dir, 'regressor_golden.npz')
     spec = [('regressor.module.layer_000.0.weight', (1024, 2193)),

