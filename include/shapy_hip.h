@@ -99,7 +99,9 @@ typedef struct ShapyConv {
                          never Winograd, 0x4000 / 0x8000 Winograd tile groups, 0x20000 Winograd K
                          loop chunk by chunk, 0x40000 / 0x80000 three / one chunk(s) of loads in
                          flight.  Speed only: every setting computes the same convolution.
-                         (0x200000: F(4x4) kernel with its 12-chunk loop unrolled, Cin = 192.)
+                         (0x200000: F(4x4) kernel with its 12-chunk loop unrolled, Cin = 192;
+                         bits 24..30: F(4x4) kernels, start delay of a CU's second workgroup in
+                         units of 128 clocks, SHAPY_TILE_W4_STAGGER(n).)
                          One bit describes DATA instead: SHAPY_TILE_WINO4 (0x100000) says that
                          wgt_wino holds F(4x4,3x3) filters (below).                             */
   int32_t dtype;      /* storage type of in / wgt / res / out: SHAPY_DTYPE_F32 (f32 MFMA, exact
@@ -120,6 +122,7 @@ typedef struct ShapyConv {
                          on `wgt` instead; SHAPY_EINVAL when the layer shape does not qualify.  */
 } ShapyConv;
 #define SHAPY_TILE_WINO4 0x100000
+#define SHAPY_TILE_W4_STAGGER(n) (((n) & 0x7f) << 24)
 
 int shapy_conv2d(const ShapyConv *desc_host, void *stream);
 

@@ -73,6 +73,11 @@ for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: con
 TILE_WINO4 = 0x100000                   # ShapyConv.wgt_wino holds F(4x4,3x3) filters (conv_wino4.hip)
 TILE_WINO4_UNROLL12 = 0x200000          # A/B knob: F(4x4) kernel with its 12-chunk loop unrolled (Cin = 192)
 
+
+def tile_w4_stagger(n):
+    """F(4x4) kernels: start delay of a CU's second workgroup, n units of 128 clocks (bits 24..30)."""
+    return (int(n) & 0x7f) << 24
+
 #: every symbol include/shapy_hip.h declares: (restype, argtypes)
 SIGNATURES = {
     'shapy_abi_version': (ctypes.c_int, []),

@@ -45,7 +45,7 @@ def hipcc():
 
 
 def _newest_dep():
-    deps = [osp.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
+    deps = [osp.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h', '.map'))]
     deps.append(osp.join(osp.dirname(HERE), 'include', 'shapy_hip.h'))
     return max(osp.getmtime(d) for d in deps)
 
@@ -72,7 +72,8 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES.items()))
-    cmd = [cc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', OUT] + objs
+    cmd = [cc, '-shared', '-fPIC', f'--offload-arch={ARCH}',
+           '-Wl,--version-script=' + osp.join(CSRC, 'exports.map'), '-o', OUT] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')

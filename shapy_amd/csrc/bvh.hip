@@ -23,6 +23,8 @@
 //     of traversal and atomic order (identical to the scan path in measure.hip and to the CPU
 //     oracle as long as no query exceeds max_collisions).
 // Compiled with -ffp-contract=off like measure.hip (bit-identical narrow-phase decisions).
+#include <stdio.h>
+
 #include <mutex>
 
 #include "tri_tri.h"
@@ -492,6 +494,18 @@ int mesh_to_mesh_bvh(const float *query, const float *target, int B, int Q, int 
     SHAPY_HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
     if (dev < 0 || dev >= 64 || !(done >> dev & 1ull)) {
+      // this library is built for gfx950 (160 KB of LDS per CU); on a device that cannot give one
+      // workgroup 128 KB + the kernel's static LDS the build kernel cannot run -- say so instead of
+      // failing inside the launch
+      int max_lds = 0;
+      SHAPY_HIP_TRY(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+      hipFuncAttributes fa;
+      SHAPY_HIP_TRY(hipFuncGetAttributes(&fa, (const void *)bvh_build_kernel));
+      if ((size_t)max_lds < BVH_LDS_BYTES + fa.sharedSizeBytes) {
+        fprintf(stderr, "shapy: mesh_to_mesh_bvh needs %zu bytes of LDS per workgroup, device %d offers %d "
+                        "(library built for gfx950)\n", BVH_LDS_BYTES + fa.sharedSizeBytes, dev, max_lds);
+        return SHAPY_EINVAL;
+      }
       SHAPY_HIP_TRY(hipFuncSetAttribute((const void *)bvh_build_kernel,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)BVH_LDS_BYTES));
       if (dev >= 0 && dev < 64) done |= 1ull << dev;

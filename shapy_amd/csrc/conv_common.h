@@ -48,6 +48,7 @@ struct ConvK {
   int pd3;                      // implicit GEMM: three chunks of global loads in flight
   int dbg;                      // -DSHAPY_WINO_TIMING builds only: ablation mask (wrong results)
   int w4_unroll12;              // tuning: F(4x4) kernel with the 12-chunk loop unrolled (Cin = 192)
+  int w4_stagger;               // F(4x4): start delay of a CU's second workgroup, units of 128 clocks
 };
 
 // Winograd F(2x2,3x3) path of the float32 3x3 / stride-1 layers (conv_wino.hip)

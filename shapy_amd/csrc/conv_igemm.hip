@@ -359,6 +359,7 @@ int conv_prepare(const ShapyConv &d, ConvK &k, int *empty) {
   k.no_allk = (d.tile & 0x20000) ? 1 : 0;
   k.dbg = 0;
   k.w4_unroll12 = 0;
+  k.w4_stagger = (d.tile >> 24) & 0x7f;       // F(4x4) kernels: SHAPY_TILE_W4_STAGGER(n)
   k.flat = flat ? 1 : 0;
   return SHAPY_OK;
 }

@@ -55,6 +55,22 @@ __device__ __forceinline__ void wino4_at4(const f32x4 (&m)[6], f32x4 (&o)[4]) {
   }
 }
 
+// Start stagger of the multiplying waves (both F(4x4) kernels).  Two workgroups share a CU and every
+// SIMD's matrix core is shared by one multiplying wave of each; launched together, both multiply at
+// the same time (each at half rate) and then both sit in their epilogue / wait for the next staged
+// chunk with the matrix cores idle.  An offset d between their multiply phases is PRESERVED from task
+// to task (whoever multiplies alone runs at full rate, so the phases neither converge nor drift), so
+// one delay at the start -- d ~ epilogue + hand-over time -- puts one workgroup's memory phase under
+// the other's MFMA phase for the whole launch.  The second workgroup of a CU is the one whose waves
+// got wave slot 1 of their SIMD (HW_ID[0]; speed only: a wrong guess costs nothing but the delay).
+__device__ __forceinline__ void wino4_start_stagger(int units) {
+  if (units <= 0) return;
+  unsigned hw_id;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+  if (hw_id & 1u)
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(2);       // 2 x 64 clocks
+}
+
 // Epilogue of a multiplying wave (both F(4x4) kernels).  The MFMAs run with the FILTER fragment as
 // the A operand and the V fragment as B, so the C layout is D[channel 4 g + r][tile l15]: a lane
 // holds ONE tile and FOUR CONSECUTIVE output channels of it in every accumulator -- the output
@@ -129,20 +145,38 @@ __device__ __forceinline__ void wino4_epilogue(const Wino4Epi &e, const f32x4 (&
     const f32x4 colv[6] = {s[0][bb], s[1][bb], s[2][bb], s[3][bb], s[4][bb], s[5][bb]};
     f32x4 y[4];
     wino4_at4(colv, y);                                           // A^T (M A)   (along y)
+    f32x4 v[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      bool ok = (a < nrow) & (bb < ncol);
-      f32x4 v = (y[a] + bias) + resv[bb & 1][a];
+      v[a] = (y[a] + bias) + resv[bb & 1][a];
       // ReLU without a branch per store and without hipcc's canonicalising second v_max:
       // max(v, 0) or max(v, -inf)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) asm("v_max_f32 %0, %1, %2" : "=v"(v[k]) : "v"(v[k]), "s"(relu_lo));
-#if defined(SHAPY_W4G_TIMING) || defined(SHAPY_WINO_TIMING)
-      if (e.dbg & 1) ok &= v[0] == 12345.678f;
-#endif
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, ok ? obase : BAD,
-                                             (a * W + bb) * out_ld * 4, 0);
+      for (int k = 0; k < 4; ++k) asm("v_max_f32 %0, %1, %2" : "=v"(v[a][k]) : "v"(v[a][k]), "v"(relu_lo));
     }
+    // The four pixels of the column are complete (four DIFFERENT register quads) before the first
+    // store is issued, and nothing may write a VGPR for two wait states after the last one:
+    // gfx950 reads the data of a 16-byte buffer store late, and hipcc (ROCm 7.2) only guards that
+    // hazard for MUBUF stores WITHOUT an SGPR offset -- a v_pk_add issued right behind
+    // `buffer_store_dwordx4 ..., s54 offen` replaced the second dword of lanes 12-15 of every
+    // 16-lane group by the NEXT pixel's value (GPU run D of round 4, profiles/r04d_*).
+    int voff[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      bool ok = (a < nrow) & (bb < ncol);
+#if defined(SHAPY_W4G_TIMING) || defined(SHAPY_WINO_TIMING)
+      if (e.dbg & 1) ok &= v[a][0] == 12345.678f;
+#endif
+      voff[a] = ok ? obase : BAD;
+    }
+    // (addresses included: no vector instruction at all between the four stores)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[a]), rs_out, voff[a],
+                                             (a * W + bb) * out_ld * 4, 0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
 
   // =========================== multiplying waves ===========================
   // wave w owns output channels n_blk + 16 w .. + 15 for ALL 36 positions
+  wino4_start_stagger(p.w4_stagger);
   const __amdgpu_buffer_rsrc_t rs_u =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt2), 0, p.wgt2_bytes, 0x00020000);
   const int g = lane >> 4, l15 = lane & 15;
@@ -198,16 +199,33 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
   auto chunk = [&](int cc, bool more) {
     wino4_lds_barrier();                     // chunk cc is staged
     const char *Vb = lds + (cc & 1) * LDS_V + frag_off;
+#ifdef SHAPY_W4_AF3
+    // THREE V-fragment buffers: the pair loaded in iteration pp overwrites the registers the MFMAs of
+    // iteration pp - 4 read (two iterations = 16 MFMAs = 512 cycles earlier), and is used in pp + 2
+    u32x4 af[3][2];
+#define W4_NXT(c) (((c) + 1) % 3)
+#else
     u32x4 af[2][2];
+#define W4_NXT(c) ((c) ^ 1)
+#endif
     af[0][0] = *reinterpret_cast<const u32x4 *>(Vb + 0 * PSTR);
     af[0][1] = *reinterpret_cast<const u32x4 *>(Vb + 1 * PSTR);
 #pragma unroll
     for (int pp = 0; pp < 36; pp += 2) {
+#ifdef SHAPY_W4_AF3
+      const int cur = (pp >> 1) % 3;
+#else
       const int cur = (pp >> 1) & 1;
+#endif
       if (pp + 2 < 36) {
-        af[cur ^ 1][0] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 2) * PSTR);
-        af[cur ^ 1][1] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 3) * PSTR);
+        af[W4_NXT(cur)][0] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 2) * PSTR);
+        af[W4_NXT(cur)][1] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 3) * PSTR);
       }
+#ifdef SHAPY_W4_PIN_AF
+      // the next pair's V fragments are REQUESTED before this pair's MFMAs (hipcc otherwise gives both
+      // pairs the same registers and sinks the reads behind the last MFMA that uses them)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       // two positions interleaved: consecutive MFMAs hit different accumulators (40-cycle
       // dependent latency vs a 32-cycle issue interval)
 #pragma unroll
@@ -232,6 +250,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
         else bload((pp + e) % R, q - 36, cc + 1, more);
       }
       __builtin_amdgcn_sched_barrier(0);
+#if defined(SHAPY_W4_AF3) && defined(SHAPY_W4_AF_KEEP)
+      // keep the fragments the PREVIOUS iteration multiplied allocated through this iteration's MFMAs
+      if (pp >= 2) asm volatile("" ::"v"(af[(cur + 2) % 3][0]), "v"(af[(cur + 2) % 3][1]));
+#endif
     }
   };
   if constexpr (KC > 0) {

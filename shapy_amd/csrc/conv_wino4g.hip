@@ -55,6 +55,7 @@ struct W4Group {
   W4Conv c[4];
   int n;
   int dbg;                 // tuning builds only (SHAPY_W4G_DBG)
+  int stagger;             // start delay of a CU's second workgroup, units of 128 clocks (conv_wino4.h)
   // schedule: slot s (= blockIdx.x / 8) of every XCD runs, for g = 0 .. n-1, the tasks
   // [first[g][s], first[g][s] + count[g][s]) of convolution g's per-XCD list (clipped to the
   // list's length on this XCD: lists differ by at most one task between XCDs)
@@ -143,16 +144,33 @@ __device__ __forceinline__ int w4g_task(const W4Group &G, const int task, int &g
     W4G_STAMP(0, 3);
     if constexpr (LAST) nxt = __builtin_amdgcn_readfirstlane(mbox[(tk + 1) & 1]);
     const char *Vb = lds + (gc & 1) * LDS_V + frag_off;
+#ifdef SHAPY_W4_AF3
+    // THREE V-fragment buffers: the pair loaded in iteration pp overwrites the registers the MFMAs of
+    // iteration pp - 4 read (two iterations = 16 MFMAs = 512 cycles earlier), and is used in pp + 2
+    u32x4 af[3][2];
+#define W4_NXT(c) (((c) + 1) % 3)
+#else
     u32x4 af[2][2];
+#define W4_NXT(c) ((c) ^ 1)
+#endif
     af[0][0] = *reinterpret_cast<const u32x4 *>(Vb + 0 * PSTR);
     af[0][1] = *reinterpret_cast<const u32x4 *>(Vb + 1 * PSTR);
 #pragma unroll
     for (int pp = 0; pp < 36; pp += 2) {
+#ifdef SHAPY_W4_AF3
+      const int cur = (pp >> 1) % 3;
+#else
       const int cur = (pp >> 1) & 1;
+#endif
       if (pp + 2 < 36) {
-        af[cur ^ 1][0] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 2) * PSTR);
-        af[cur ^ 1][1] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 3) * PSTR);
+        af[W4_NXT(cur)][0] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 2) * PSTR);
+        af[W4_NXT(cur)][1] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 3) * PSTR);
       }
+#ifdef SHAPY_W4_PIN_AF
+      // the next pair's V fragments are REQUESTED before this pair's MFMAs (hipcc otherwise gives both
+      // pairs the same registers and sinks the reads behind the last MFMA that uses them)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(
@@ -174,6 +192,10 @@ __device__ __forceinline__ int w4g_task(const W4Group &G, const int task, int &g
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+#if defined(SHAPY_W4_AF3) && defined(SHAPY_W4_AF_KEEP)
+      // keep the fragments the PREVIOUS iteration multiplied allocated through this iteration's MFMAs
+      if (pp >= 2) asm volatile("" ::"v"(af[(cur + 2) % 3][0]), "v"(af[(cur + 2) % 3][1]));
+#endif
     }
     ++gc;
   };
@@ -339,6 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4g_kernel(W4Group G) {
   }
 
   // =========================== multiplying waves ===========================
+  wino4_start_stagger(G.stagger);
   wino4_lds_barrier();                         // opening barrier
   int cur = __builtin_amdgcn_readfirstlane(mbox[0]);
   if (cur < 0) return;
@@ -361,6 +384,9 @@ int conv2d_wino4_group(const ConvK *ks, int n, hipStream_t s) {
   W4Group G;
   G.n = n;
   G.dbg = 0;
+  G.stagger = 0;
+  for (int i = 0; i < n; ++i)
+    if (ks[i].w4_stagger > G.stagger) G.stagger = ks[i].w4_stagger;
 #ifdef SHAPY_W4G_TIMING
   G.dbg = getenv("SHAPY_W4G_DBG") ? atoi(getenv("SHAPY_W4G_DBG")) : 0;
 #endif
@@ -389,13 +415,16 @@ int conv2d_wino4_group(const ConvK *ks, int n, hipStream_t s) {
       G.c[j] = G.c[j - 1];
       G.c[j - 1] = tmp;
     }
-  static int n_cu = 0;
+  // compute units of the CURRENT device (cached per device: ranks of one process may drive
+  // different GPUs)
+  static int n_cu_dev[64] = {};
+  int dev = 0;
+  SHAPY_HIP_TRY(hipGetDevice(&dev));
+  int n_cu = (dev >= 0 && dev < 64) ? __atomic_load_n(&n_cu_dev[dev], __ATOMIC_RELAXED) : 0;
   if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    SHAPY_HIP_TRY(hipGetDevice(&dev));
-    SHAPY_HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    SHAPY_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n_cu <= 0) n_cu = 256;
+    if (dev >= 0 && dev < 64) __atomic_store_n(&n_cu_dev[dev], n_cu, __ATOMIC_RELAXED);
   }
   // two resident workgroups per CU (73.7 KB LDS, 256 VGPRs); slots per XCD: at most 64, and not
   // more than the longest per-XCD list needs

@@ -232,12 +232,19 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
     }
     // explicit dependencies on ops of OTHER lanes (the plan's happens-before graph: ops of one lane
     // are ordered by their stream): wait for the producers' events before this op ...
-    if (multi_stream)
-      for (int w = 0; w < 3; ++w)
-        if (o.wait[w] >= 0) {
-          if (o.wait[w] >= N_EVENTS) return SHAPY_EINVAL;
-          SHAPY_HIP_TRY(hipStreamWaitEvent(s, L->ev[o.wait[w]], 0));
+    // (a launch group starts all its members at once: the waits of EVERY member come first)
+    if (multi_stream) {
+      const int n_members = (o.type == SHAPY_OP_CONV && o.group > 1) ? o.group : 1;
+      if (idx + n_members > n_ops) return SHAPY_EINVAL;
+      for (int m = 0; m < n_members; ++m)
+        for (int w = 0; w < 3; ++w) {
+          const int e = ops[idx + m].wait[w];
+          if (e >= 0) {
+            if (e >= N_EVENTS) return SHAPY_EINVAL;
+            SHAPY_HIP_TRY(hipStreamWaitEvent(s, L->ev[e], 0));
+          }
         }
+    }
     const int idx_first = idx;
     auto buf = [&](int64_t off) -> char * {
       return off < 0 ? nullptr : (char *)ws + off * (int64_t)B * esz;

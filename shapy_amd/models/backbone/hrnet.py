@@ -501,9 +501,23 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.dag_aux = os.environ.get('SHAPY_DAG_AUX', '0') == '1'
         self.dag_no_barriers = os.environ.get('SHAPY_DAG_NO_BARRIERS', '0') == '1'
         self.dag_balance = os.environ.get('SHAPY_DAG_BALANCE', '0') == '1'
+        #: per-layer demotions {op name: 'winograd' (F(2x2)) | 'direct'}: the caller's own entries AND
+        #: what the guard added for the current weights (the guard never removes a caller's entry)
         self.layer_algo = {}
+        self._guard_demotions = {}       # the guard's share of layer_algo (dropped on re-calibration)
         self.wino_guard = os.environ.get('SHAPY_WINO_GUARD', '1') != '0'
         self.wino_budget = 2e-5          # rms(winograd - direct) / rms(direct) per layer
+        #: probe of the automatic calibration: 'fixed' (default) = four SEEDED synthetic crops of the
+        #: input's size -- the same on every rank and in every run, so that all ranks compile the same
+        #: plan and features stay bit-identical between them; 'batch' = up to 8 images of the first
+        #: batch (round 3).  ``calibrate(x)`` on images of your own is always available.
+        self.wino_guard_probe = os.environ.get('SHAPY_WINO_GUARD_PROBE', 'fixed')
+        #: runtime tripwire: > 0 = every that many forwards two images of the LIVE batch are re-checked
+        #: layer by layer (one extra pass over the op list with host syncs: ~30 ms) and layers over
+        #: budget are demoted; 0 = off (default: the guard judges weights, not images)
+        self.wino_guard_recheck_every = int(os.environ.get('SHAPY_WINO_GUARD_RECHECK', '0'))
+        self._n_forward = 0
+        self._capture_warned = False
         self.calibration_report = None
         self._calibrated_ver = None
         self._engine_ver = None
@@ -607,6 +621,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         ``load_state_dict`` and after ``.to()`` / ``.cuda()``."""
         self._engine = {}
         self._calibrated_ver = None
+        self._drop_guard_demotions()
         self._drop_version_cache()
 
     def _apply(self, fn, *a, **k):
@@ -991,12 +1006,30 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                     log(f'Winograd guard: {name}: {e[1]} error {e[2]:.2e} rms-relative '
                         f'(max {e[3]:.2e}) > budget {budget:.1e} on the probe batch -> {to}')
                     self.layer_algo[name] = to
+                    self._guard_demotions[name] = to
                 report['demoted'] = dict(self.layer_algo)
         finally:
             pass
         self.calibration_report = report
         self._calibrated_ver = self._weights_version()
         return report
+
+    def _drop_guard_demotions(self):
+        """New weights: what the guard demoted for the OLD ones is void; the caller's own entries stay."""
+        for k, v in self._guard_demotions.items():
+            if self.layer_algo.get(k) == v:
+                del self.layer_algo[k]
+        self._guard_demotions = {}
+
+    def _guard_probe(self, x):
+        """Probe images of the automatic calibration (``wino_guard_probe``)."""
+        B, _, H, W = x.shape
+        if self.wino_guard_probe == 'batch':
+            return x[:min(B, 8)]
+        from ...utils import synthetic as syn
+        side = max(H, W)
+        p = torch.from_numpy(syn.synthetic_images(4, side, 7001)).to(x.device)
+        return p[:, :, :H, :W].contiguous()
 
     @staticmethod
     def _op_channels(eng, name):
@@ -1066,10 +1099,25 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             raise ValueError('HRNet input height/width must be multiples of 32')
         x = x.contiguous().float()
         use_graph = self.use_graph is True or (self.use_graph == 'auto' and B <= self.graph_max_batch)
-        if (self.wino_guard and self.compute_dtype == 'f32' and self.conv_algo in ('winograd', 'winograd4', 'auto')
-                and self._calibrated_ver != self._weights_version()):
-            self.layer_algo = {}
-            self.calibrate(x[:min(B, 8)], graph=use_graph)   # a few images show a misbehaving layer
+        self._n_forward += 1
+        if self.wino_guard and self.compute_dtype == 'f32' and self.conv_algo in ('winograd', 'winograd4', 'auto'):
+            stale = self._calibrated_ver != self._weights_version()
+            recheck = (self.wino_guard_recheck_every > 0 and not stale
+                       and self._n_forward % self.wino_guard_recheck_every == 0)
+            if (stale or recheck) and torch.cuda.is_current_stream_capturing():
+                # the calibration synchronises with the host (per-layer error readback): it cannot
+                # run inside a caller's stream capture
+                if not self._capture_warned:
+                    self._capture_warned = True
+                    import logging
+                    logging.getLogger('shapy_amd.hrnet').warning(
+                        'Winograd guard skipped: forward() called under stream capture before the '
+                        'weights were calibrated -- call calibrate() once outside the capture')
+            elif stale:
+                self._drop_guard_demotions()
+                self.calibrate(self._guard_probe(x), graph=use_graph)
+            elif recheck:
+                self.calibrate(x[:min(B, 2)], graph=use_graph)     # only ever ADDS demotions
         eng = self._compile(H, W, x.device, graph=use_graph)
         if use_graph:
             return {'concat': self._forward_graph(lib, eng, x)}

@@ -676,6 +676,45 @@ def test_hrnet_event_driven_plan_equals_barrier_plan(network, B, size, graph):
     assert all(torch.equal(g, ref) for g in got)
 
 
+def test_hrnet_two_host_threads_on_two_streams_bit_identical(network):
+    """Two host threads issue forwards concurrently, each on its own stream: the executor serialises
+    the ENQUEUE of a forward (one process-wide lock around the whole issue incl. its event records /
+    waits on the shared side streams), every caller stream has its own workspace -- results equal the
+    single-threaded ones bit for bit."""
+    import threading
+    from shapy_amd.models.backbone import hrnet as hrnet_mod
+    from shapy_amd.utils import synthetic as syn
+    bb = network.backbone
+    keep = bb.multi_stream
+    bb.multi_stream, bb.conv_algo = True, hrnet_mod.DEFAULT_CONV_ALGO
+    xs = [torch.from_numpy(syn.synthetic_images(3, 96, 40 + i)).cuda() for i in range(2)]
+    try:
+        with torch.no_grad():
+            refs = [bb(x)['concat'].clone() for x in xs]
+        torch.cuda.synchronize()
+        outs, errs = [None, None], []
+
+        def work(i):
+            try:
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st), torch.no_grad():
+                    got = [bb(xs[i])['concat'].clone() for _ in range(6)]
+                st.synchronize()
+                outs[i] = got
+            except Exception as e:               # noqa: BLE001
+                errs.append(e)
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+    finally:
+        bb.multi_stream, bb.conv_algo = keep, 'direct'
+    for i in range(2):
+        assert all(torch.equal(g, refs[i]) for g in outs[i])
+
+
 def test_conv2d_group_c_abi_matches_single_launches():
     """shapy_conv2d_group through the C-ABI: groups of 1-4 layers incl. partly filled workgroups,
     a channel-offset epilogue, Cout = 144 (the generic XCD split), more tasks than workgroup slots;

@@ -603,6 +603,31 @@ def test_bench_refuses_a_world_size_mismatch():
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
 
 
+def test_winograd_guard_keeps_the_callers_layer_overrides(hrnet):
+    """The guard's demotions are dropped when the weights change; entries the CALLER put into
+    layer_algo (or changed afterwards) survive; the fixed calibration probe is the same tensor on
+    every call (every rank compiles the same plan)."""
+    keep = dict(hrnet.layer_algo), dict(hrnet._guard_demotions)
+    try:
+        hrnet.layer_algo = {'stage2.0.branches.0.0.conv1': 'direct'}              # the caller's
+        for name, to in (('stage3.0.branches.1.0.conv2', 'winograd'), ('stage3.1.branches.2.1.conv1', 'direct')):
+            hrnet.layer_algo[name] = to                                            # what calibrate() does
+            hrnet._guard_demotions[name] = to
+        hrnet.layer_algo['stage3.0.branches.1.0.conv2'] = 'direct'                # caller tightens one
+        hrnet._drop_guard_demotions()
+        assert hrnet.layer_algo == {'stage2.0.branches.0.0.conv1': 'direct',
+                                    'stage3.0.branches.1.0.conv2': 'direct'}
+        assert hrnet._guard_demotions == {}
+        x = torch.zeros(3, 3, 64, 96)
+        p1, p2 = hrnet._guard_probe(x), hrnet._guard_probe(x)
+        assert p1.shape == (4, 3, 64, 96) and torch.equal(p1, p2) and float(p1.std()) > 0.5
+        hrnet.wino_guard_probe = 'batch'
+        assert hrnet._guard_probe(x).shape == (3, 3, 64, 96)
+    finally:
+        hrnet.wino_guard_probe = 'fixed'
+        hrnet.layer_algo, hrnet._guard_demotions = keep
+
+
 def test_grouped_branch_levels_plan(hrnet):
     """conv_algo='winograd4' with group_branches: the branch convs of every HighResolutionModule are
     listed level by level on lane 0, the first op of a level carries the group size, the ops of a
