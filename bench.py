@@ -932,6 +932,14 @@ def main():
     if rank == 0:
         if finish is not None:
             res = finish(res)
+        # the JSON line is the LAST thing on stdout: whatever native libraries (RCCL prints its library
+        # path through C stdio) still hold in their buffers goes out first
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(res), flush=True)
 
 
