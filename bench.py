@@ -229,13 +229,20 @@ STUB = {'on': False}      # --cpu-stub (tests/test_host_cpu.py): gloo ranks, stu
 
 
 def barrier():
-    """RCCL barrier on this rank's own GPU (named explicitly: no device guessing)."""
+    """Barrier of the control plane.  gloo (default, N > 1): a host barrier -- every caller brackets it
+    with device_sync(); nccl (--control-backend nccl): an RCCL barrier on this rank's own GPU."""
     import torch
     import torch.distributed as dist
-    if STUB['on']:
+    if dist.get_backend() == 'gloo':
         dist.barrier()
     else:
         dist.barrier(device_ids=[torch.cuda.current_device()])
+
+
+def control_device():
+    """Where the control plane's small tensors (timings) live: host for gloo, this GPU for nccl."""
+    import torch.distributed as dist
+    return 'cpu' if (STUB['on'] or not dist.is_initialized() or dist.get_backend() == 'gloo') else 'cuda'
 
 
 def device_sync():
@@ -337,7 +344,7 @@ def run_measurements(args, rank, world):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        tmax = torch.tensor([dt], dtype=torch.float64, device=control_device())
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
@@ -642,17 +649,18 @@ def run_regressor(args, rank, world, local_rank):
     x_np = syn.synthetic_images(B, args.size, 100 + rank)
     x = torch.from_numpy(x_np).to(dev)
     force_gather = bool(getattr(args, 'force_gather', False)) and world == 1 and not stub
-    if force_gather:
-        # one-GPU rehearsal of the N-rank step: a world-size-1 RCCL group, so the collective, c10d's
-        # RCCL stream and the deferred join of BetasGatherer all exist in THIS process
+    gather_mode = getattr(args, 'gather_mode', None)
+    if force_gather and gather_mode in ('work', 'side'):
+        # one-GPU rehearsal of the c10d variants of the N-rank step: a world-size-1 RCCL process group,
+        # so the collective, c10d's RCCL stream and the deferred join all exist in THIS process
+        # (the default mode 'rccl' needs no process group for one rank: shapy_amd/rccl.py)
         import socket
         with socket.socket() as sk:
             sk.bind(('127.0.0.1', 0))
             port = sk.getsockname()[1]
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', init_method='env://')
-    gatherer = parallel.BetasGatherer(world, force=force_gather,
-                                      mode=getattr(args, 'gather_mode', None))
+    gatherer = parallel.BetasGatherer(world, force=force_gather, mode=gather_mode)
     # the timed region includes the D2H of the betas (async copy into pinned host
     # memory on the compute stream; the closing synchronize covers the last one)
     betas_host = torch.empty(B, 10, dtype=torch.float32)
@@ -693,26 +701,28 @@ def run_regressor(args, rank, world, local_rank):
     h0.remove(); h1.remove()
     per_rank = None
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        cdev = control_device()
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        own = torch.tensor([B * args.steps / own_dt], dtype=torch.float64, device=dev)
+        own = torch.tensor([B * args.steps / own_dt], dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(own) for _ in range(world)]
         dist.all_gather(allr, own)
         per_rank = [float(t.item()) for t in allr]
     assert betas.shape == (world * B, 10)
     if force_gather:
         assert torch.equal(betas, out['stage_02']['betas']) and gatherer.issued == args.steps + args.warmup
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
     assert torch.equal(betas_host, out['stage_02']['betas'].cpu())      # the D2H copy landed
     if world > 1:      # the gathered tensor really holds every rank's betas: own shard in place
         assert torch.equal(betas[rank * B:(rank + 1) * B], out['stage_02']['betas'])
         # ... and every OTHER rank's shard is that rank's own result (checked on rank 0 against
         # the betas each rank sends separately)
-        mine = out['stage_02']['betas'].contiguous()
+        mine = out['stage_02']['betas'].contiguous().to(control_device())
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        assert torch.equal(betas, torch.cat(every, dim=0))
+        assert torch.equal(betas.to(mine.device), torch.cat(every, dim=0))
 
     if stub:
         if rank != 0:
@@ -820,8 +830,8 @@ def run_regressor(args, rank, world, local_rank):
         res['rccl_ranks'] = 1
         res['force_gather'] = {'mode': gatherer.mode, 'issued': gatherer.issued,
                                'joined_by_next_step': gatherer.deferred_waits,
-                               'note': 'world-size-1 RCCL group: the all_gather, the RCCL stream and '
-                                       'the deferred join of the N-rank step on ONE GPU'}
+                               'note': 'world-size-1 RCCL communicator: the all_gather of the N-rank step on '
+                                       'ONE GPU (work / side: through c10d, with its RCCL stream)'}
     if world == 1 and not getattr(args, 'no_also', False) and not getattr(args, '_sub', False):
         res['also'] = also_records(args, net, x)
 
@@ -874,8 +884,12 @@ def main():
                     help='N = 1 only: create a world-size-1 RCCL group and take BetasGatherer\'s '
                          'collective path (rehearsal of the N-rank step on one GPU; the line says '
                          '"rccl_ranks": 1)')
-    ap.add_argument('--gather-mode', default=None, choices=['work', 'side'],
-                    help='BetasGatherer issue mode (shapy_amd/parallel.py; default: work)')
+    ap.add_argument('--gather-mode', default=None, choices=['rccl', 'work', 'side'],
+                    help='BetasGatherer issue mode (shapy_amd/parallel.py; default: rccl = ncclAllGather '
+                         'called directly on the compute stream)')
+    ap.add_argument('--control-backend', default='gloo', choices=['gloo', 'nccl'],
+                    help='torch.distributed backend of the control plane at N > 1 (barriers, timing '
+                         'reduction, RCCL id exchange); the betas all-gather is RCCL either way')
     ap.add_argument('--group-branches', default=None, choices=['auto', 'on', 'off'],
                     help='persistent grouped F(4x4) launches per depth level of a module '
                          '(HighResolutionNet.group_branches)')
@@ -906,8 +920,12 @@ def main():
         import datetime
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # explicit timeout: a rank that dies must fail the job in minutes, not hang the node
-        dist.init_process_group('gloo' if STUB['on'] else 'nccl', init_method='env://',
-                                timeout=datetime.timedelta(seconds=600))
+        # control plane (rendezvous, barriers, max-over-ranks of the timing, the 128-byte RCCL id):
+        # gloo by default -- the DATA plane, the all-gather of the betas, is RCCL called directly on
+        # the compute stream (shapy_amd/rccl.py); c10d's NCCL backend would add a stream per process,
+        # which alone costs the four-lane backbone 17 % (profiles/r04j_*)
+        backend = 'gloo' if STUB['on'] else args.control_backend
+        dist.init_process_group(backend, init_method='env://', timeout=datetime.timedelta(seconds=600))
     if (rank == 0 and not STUB['on']
             and not osp.exists(osp.join(ROOT, 'shapy_amd', 'csrc', 'libshapy_hip.so'))):
         from shapy_amd import build as hip_build      # fresh checkout: the library is git-ignored

@@ -51,21 +51,23 @@ class BetasGatherer:
     def __init__(self, world=None, group=None, force=False, mode=None):
         """force: take the collective path even for ONE rank (bench.py --force-gather: a world-size-1
         RCCL group exercises the stream / event structure of the N-rank path on a single GPU).
-        mode: 'work' (default) = the collective is issued from the CALLER's stream with
-        async_op=True -- c10d runs it on its own RCCL stream behind an event of the caller's stream,
-        and the Work handle is joined (a stream-side wait, not a host wait) at the next call;
-        'side' = rounds 1-3: a private side stream around a blocking call.  Both defer the join by
-        one step; 'work' needs no stream of our own (HIP multiplexes a process's streams onto a few
-        hardware queues: every extra stream costs the four-lane backbone).
+        mode: 'rccl' (default) = ncclAllGather called directly on the CALLER's stream
+        (shapy_amd/rccl.py): no extra stream at all -- measured on one GPU with a world-size-1
+        group, c10d's own RCCL stream alone cost the four-lane backbone 17 % (4,140-4,170 vs 5,020
+        images/s, profiles/r04j_*: HIP multiplexes a process's streams onto a few hardware queues);
+        'work' = c10d, async_op=True from the caller's stream, the Work handle joined (a stream-side
+        wait) at the next call; 'side' = rounds 1-3: c10d on a private side stream.  'work' / 'side'
+        defer the join by one step; with 'rccl' the result is simply next in stream order.
         SHAPY_GATHER_MODE overrides the default."""
         import os
         self.group = group
         self.world = world if world is not None else (
             dist.get_world_size(group) if dist.is_initialized() else 1)
         self.force = bool(force)
-        self.mode = mode or os.environ.get('SHAPY_GATHER_MODE', 'work')
-        if self.mode not in ('work', 'side'):
+        self.mode = mode or os.environ.get('SHAPY_GATHER_MODE', 'rccl')
+        if self.mode not in ('rccl', 'work', 'side'):
             raise ValueError(f'unknown gather mode {self.mode!r}')
+        self._comm = None             # mode 'rccl': shapy_amd.rccl.RcclComm, created on first use
         self._stream = None
         self._pending = None          # (out, event | Work | None) of the gather still in flight
         self.issued = 0
@@ -94,7 +96,18 @@ class BetasGatherer:
         local = local.contiguous()
         out = local.new_empty((self.world * local.shape[0],) + tuple(local.shape[1:]))
         self.issued += 1
-        if local.is_cuda and self.mode == 'work':
+        if local.is_cuda and self.mode == 'rccl':
+            # RCCL called directly on the CALLER's stream (shapy_amd/rccl.py): no stream of its own,
+            # no event -- the gather is one more kernel behind the step's tail
+            if self._comm is None:
+                from .rccl import RcclComm
+                self._comm = RcclComm(world=self.world if not dist.is_initialized() else None,
+                                      group=self.group)
+                if self._comm.world != self.world:
+                    raise RuntimeError(f'BetasGatherer(world={self.world}) on a group of {self._comm.world}')
+            out = self._comm.all_gather(local)
+            self._pending = (out, None, local)
+        elif local.is_cuda and self.mode == 'work':
             work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
             self._pending = (out, work, local)       # `local` stays referenced until the join
         elif local.is_cuda:

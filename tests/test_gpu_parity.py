@@ -1283,7 +1283,7 @@ def _nccl_one_rank_worker(port, q):
     dist.init_process_group('nccl', init_method='env://')
     try:
         ok = {}
-        for mode in ('work', 'side'):
+        for mode in ('rccl', 'work', 'side'):
             gat = parallel.BetasGatherer(1, force=True, mode=mode)
             side = torch.cuda.Stream()
             with torch.cuda.stream(side):              # a non-default caller stream, as in serving
@@ -1299,9 +1299,10 @@ def _nccl_one_rank_worker(port, q):
 
 
 def test_rccl_forced_gather_one_rank_both_modes():
-    """bench.py --force-gather's path: a world-size-1 RCCL group on ONE GPU runs the collective, the
-    RCCL stream and the deferred join of the N-rank path -- both issue modes of BetasGatherer
-    ('work': async collective from the caller's stream; 'side': private side stream)."""
+    """bench.py --force-gather's path: a world-size-1 RCCL group on ONE GPU runs the collective of the
+    N-rank path in all three issue modes of BetasGatherer ('rccl', the default: ncclAllGather called
+    directly on the caller's stream, shapy_amd/rccl.py; 'work': c10d async collective from the
+    caller's stream; 'side': c10d on a private side stream)."""
     _need_gpu()
     import socket
     import torch.multiprocessing as mp
@@ -1314,7 +1315,7 @@ def test_rccl_forced_gather_one_rank_both_modes():
     p.start()
     res = q.get(timeout=300)
     p.join(timeout=60)
-    assert res == {'work': True, 'side': True}, res
+    assert res == {'rccl': True, 'work': True, 'side': True}, res
 
 
 def test_rccl_allgather_two_ranks():
