@@ -710,6 +710,9 @@ def run_regressor(args, rank, world, local_rank):
         dist.all_gather(allr, own)
         per_rank = [float(t.item()) for t in allr]
     assert betas.shape == (world * B, 10)
+    betas_all = betas.clone()
+    gatherer.close()                   # (the communicator goes before the process group does)
+    betas = betas_all
     if force_gather:
         assert torch.equal(betas, out['stage_02']['betas']) and gatherer.issued == args.steps + args.warmup
         if dist.is_initialized():

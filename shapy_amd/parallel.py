@@ -132,6 +132,14 @@ class BetasGatherer:
         self.wait()
         return out
 
+    def close(self):
+        """Joins the gather in flight and destroys the RCCL communicator of mode 'rccl' (call before
+        the process group goes away; idempotent)."""
+        self.wait()
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None
+
 
 def gather_variable(local, group=None):
     """all_gather for shards of different length (last ranks may hold one item less)."""
