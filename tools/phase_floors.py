@@ -1,7 +1,7 @@
 """Lower bounds per phase of the backbone forward next to the measured wall times.
 
 For every epoch group of the plan (stem + layer1, stage 2, stage 3, stage 4, head): the FLOPs the
-matrix cores execute / the sustained f32 MFMA rate (141 TFLOP/s, profiles/r01_mfma_peak.txt) and the
+matrix cores execute / the nominal dense f32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) and the
 bytes every conv must move (input + output + residual + weights, each once) / 4.7 TB/s (mixed
 read / write rate reached by the HBM-bound layers) -- the larger of the two is the phase's floor.
 
@@ -76,7 +76,7 @@ def main():
     print(f'{"phase":40s} {"launches":>8s} {"MFMA floor":>11s} {"HBM floor":>10s} {"measured":>9s}   (ms, B = {B})')
     tot = [0.0, 0.0, 0.0]
     for k, v in phases.items():
-        t_m, t_h = v['flop'] / 141e12 * 1e3, v['bytes'] / 4.7e12 * 1e3
+        t_m, t_h = v['flop'] / 157.3e12 * 1e3, v['bytes'] / 4.7e12 * 1e3
         w = walls.get(k, float('nan')) / 1e3
         tot[0] += max(t_m, t_h); tot[1] += w if w == w else 0.0
         print(f'{k:40s} {v["n"]:8d} {t_m:11.2f} {t_h:10.2f} {w:9.2f}')

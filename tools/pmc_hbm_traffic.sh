@@ -12,7 +12,7 @@ export SHAPY_WINO_GUARD=0 SHAPY_GROUP_BRANCHES=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $grp | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d "$ROOT/$OUT/$tag" -- \
-      python "$ROOT/bench.py" --steps 2 --warmup 1 --single-stream --no-cpu-baseline --dtype $DT --algo $ALGO --batch $BATCH \
+      python "$ROOT/bench.py" --steps 2 --warmup 1 --single-stream --no-cpu-baseline --no-also --dtype $DT --algo $ALGO --batch $BATCH \
       > "$ROOT/$OUT/$tag.log" 2>&1
 done
 cd "$ROOT"
