@@ -173,6 +173,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
   // =========================== multiplying waves ===========================
   // wave w owns output channels n_blk + 16 w .. + 15 for ALL 36 positions
   wino4_start_stagger(p.w4_stagger);
+#ifdef SHAPY_W4_PRIO
+  __builtin_amdgcn_s_setprio(SHAPY_W4_PRIO);    // A/B: multiplying waves above the staging waves
+#endif
   const __amdgpu_buffer_rsrc_t rs_u =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt2), 0, p.wgt2_bytes, 0x00020000);
   const int g = lane >> 4, l15 = lane & 15;

@@ -362,6 +362,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4g_kernel(W4Group G) {
 
   // =========================== multiplying waves ===========================
   wino4_start_stagger(G.stagger);
+#ifdef SHAPY_W4_PRIO
+  __builtin_amdgcn_s_setprio(SHAPY_W4_PRIO);
+#endif
   wino4_lds_barrier();                         // opening barrier
   int cur = __builtin_amdgcn_readfirstlane(mbox[0]);
   if (cur < 0) return;
