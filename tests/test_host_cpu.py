@@ -628,6 +628,39 @@ def test_winograd_guard_keeps_the_callers_layer_overrides(hrnet):
         hrnet.layer_algo, hrnet._guard_demotions = keep
 
 
+def test_rccl_binding_loads_and_bench_counts_launch_groups(hrnet):
+    """shapy_amd/rccl.py binds the librccl.so that ships with torch (symbols only: no communicator
+    without a GPU); bench.launches_per_forward counts a launch group as ONE launch."""
+    import bench
+    from shapy_amd import parallel, rccl
+    lib = rccl._load()
+    for sym in ('ncclGetUniqueId', 'ncclCommInitRank', 'ncclAllGather', 'ncclCommDestroy'):
+        assert hasattr(lib, sym)
+    assert ctypes_sizeof_unique_id() == 128
+    g = parallel.BetasGatherer(1)
+    assert g.mode == 'rccl' and g(torch.ones(2, 10)).shape == (2, 10)      # one rank, not forced: identity
+    with pytest.raises(ValueError):
+        parallel.BetasGatherer(2, mode='nonsense')
+    keep = hrnet.conv_algo, hrnet.wino4_min_hw, hrnet.group_branches
+    try:
+        hrnet.conv_algo, hrnet.wino4_min_hw = 'winograd4', 7
+        hrnet.group_branches = False
+        n_single = bench.launches_per_forward(hrnet._build_plan(224, 224))
+        hrnet.group_branches = True
+        P = hrnet._build_plan(224, 224)
+        n_group = bench.launches_per_forward(P)
+    finally:
+        hrnet.conv_algo, hrnet.wino4_min_hw, hrnet.group_branches = keep
+    assert n_single == len(P.ops) == 332
+    assert n_group == n_single - sum(o['group'] - 1 for o in P.ops if o['group'] > 1) == 188
+
+
+def ctypes_sizeof_unique_id():
+    import ctypes
+    from shapy_amd import rccl
+    return ctypes.sizeof(rccl._UniqueId)
+
+
 def test_grouped_branch_levels_plan(hrnet):
     """conv_algo='winograd4' with group_branches: the branch convs of every HighResolutionModule are
     listed level by level on lane 0, the first op of a level carries the group size, the ops of a
