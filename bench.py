@@ -132,9 +132,16 @@ def pmc_traffic(batch, size, dtype='f32', algo='direct', any_algo=False):
         same_algo = h.get('algo', 'direct') == (algo if dtype == 'f32' else h.get('algo', 'direct'))
         if (h.get('batch') == batch and h.get('size') == size and h.get('dtype', 'f32') == dtype
                 and (same_algo or any_algo)):
-            return {'bytes_as_reported': h['as_reported'], 'bytes_fetch_x2_corrected':
-                    h['fetch_x2_corrected'], 'conv_algo': h.get('algo', 'direct'),
-                    'source': osp.relpath(f, ROOT)}
+            out = {'bytes_as_reported': h['as_reported'], 'bytes_fetch_x2_corrected':
+                   h['fetch_x2_corrected'], 'conv_algo': h.get('algo', 'direct'),
+                   'source': osp.relpath(f, ROOT)}
+            m = d.get('mfma')
+            if m and m.get('GRBM_GUI_ACTIVE_sum_over_8_xcd'):
+                # matrix-core busy share of all SIMD cycles over the same (single-stream) pass:
+                # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE summed over the 8 XCDs x 128 SIMDs each)
+                out['mfma_busy_frac_of_simd_cycles'] = (
+                    m['SQ_VALU_MFMA_BUSY_CYCLES_sum'] / (m['GRBM_GUI_ACTIVE_sum_over_8_xcd'] * 128.0))
+            return out
     return None
 
 

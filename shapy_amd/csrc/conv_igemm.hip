@@ -416,6 +416,10 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   // workgroups (+4..12 %, profiles/conv_bench_r01h_32x64.txt)
   if (!(d.tile & 0xff) && !bf16 && !x6 && kq == 8 && k.ups == 1 && k.Cout % 64 == 0 && k.M <= 12544)
     tile = SHAPY_TILE_32x64;
+  // one N tile only (Cout = 64: conv2 of the stem, 3x3 / stride 2 at 112x112): the 32-row tile again --
+  // 134 vs 149 us at B = 64 (profiles/r04j_conv_bench_direct_tile_sweep.txt)
+  if (!(d.tile & 0xff) && !bf16 && !x6 && kq == 8 && k.ups == 1 && k.Cout == 64 && k.stride == 2)
+    tile = SHAPY_TILE_32x64;
   if (k.ups != 1 && tile != SHAPY_TILE_64x48 && tile != SHAPY_TILE_64x64)
     tile = (k.Cout % 64 == 0 && k.Cout % 48 != 0) ? SHAPY_TILE_64x64 : SHAPY_TILE_64x48;
   if (flat) { tile = SHAPY_TILE_64x48; kq = 4; }
