@@ -99,12 +99,8 @@ class BetasGatherer:
         if local.is_cuda and self.mode == 'rccl':
             # RCCL called directly on the CALLER's stream (shapy_amd/rccl.py): no stream of its own,
             # no event -- the gather is one more kernel behind the step's tail
-            if self._comm is None:
-                from .rccl import RcclComm
-                self._comm = RcclComm(world=self.world if not dist.is_initialized() else None,
-                                      group=self.group)
-                if self._comm.world != self.world:
-                    raise RuntimeError(f'BetasGatherer(world={self.world}) on a group of {self._comm.world}')
+            if self._comm is None and not self._init_rccl():
+                return self._call_c10d(local, out)          # every rank fell back to mode 'work'
             out = self._comm.all_gather(local)
             self._pending = (out, None, local)
         elif local.is_cuda and self.mode == 'work':
@@ -125,6 +121,49 @@ class BetasGatherer:
             chunks = list(out.chunk(self.world, dim=0))
             dist.all_gather(chunks, local, group=self.group)
             self._pending = (out, None)
+        return out
+
+    def _init_rccl(self):
+        """Creates the direct RCCL communicator on first use.  Returns False when ANY rank could not
+        (agreed over the control plane, so that all ranks take the same path): the gatherer then
+        falls back to c10d's NCCL backend (mode 'work'; a 'nccl' subgroup is created when the default
+        process group is not one) -- slower per step (an extra stream), but a working collective."""
+        import logging
+        import os
+        from .rccl import RcclComm
+        ok, err = 1, None
+        try:
+            if os.environ.get('SHAPY_RCCL_FORCE_FAIL') == '1':
+                raise RuntimeError('SHAPY_RCCL_FORCE_FAIL=1 (test hook)')
+            self._comm = RcclComm(world=self.world if not dist.is_initialized() else None,
+                                  group=self.group)
+            if self._comm.world != self.world:
+                raise RuntimeError(f'BetasGatherer(world={self.world}) on a group of {self._comm.world}')
+        except Exception as e:                 # noqa: BLE001 -- any failure means "fall back"
+            ok, err = 0, e
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dev = 'cuda' if dist.get_backend(self.group) == 'nccl' else 'cpu'
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ok = int(flag.item())
+        if ok:
+            return True
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None
+        logging.getLogger('shapy_amd.parallel').warning(
+            'direct RCCL communicator unavailable (%s): falling back to torch.distributed\'s NCCL '
+            'backend for the betas all-gather (one extra stream per process)', err)
+        if not dist.is_initialized():
+            raise RuntimeError('no RCCL communicator and no process group to fall back to') from err
+        self.mode = 'work'
+        if dist.get_backend(self.group) != 'nccl':
+            self.group = dist.new_group(backend='nccl')          # collective: every rank is here
+        return False
+
+    def _call_c10d(self, local, out):
+        work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
+        self._pending = (out, work, local)
         return out
 
     def gather(self, local):

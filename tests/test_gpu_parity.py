@@ -1293,6 +1293,15 @@ def _nccl_one_rank_worker(port, q):
             torch.cuda.synchronize()
             ok[mode] = (all(torch.equal(o, x * 2) for o, x in zip(outs, xs)) and last is outs[-1]
                         and gat.issued == 3 and gat.deferred_waits == 2 and gat.wait() is None)
+            gat.close()
+        # the direct communicator "fails" on every rank -> the gatherer agrees on c10d (mode 'work')
+        os.environ['SHAPY_RCCL_FORCE_FAIL'] = '1'
+        gat = parallel.BetasGatherer(1, force=True, mode='rccl')
+        x = torch.randn(8, 10, device='cuda')
+        got = gat.gather(x)
+        torch.cuda.synchronize()
+        ok['fallback'] = bool(torch.equal(got, x) and gat.mode == 'work')
+        del os.environ['SHAPY_RCCL_FORCE_FAIL']
         q.put(ok)
     finally:
         dist.destroy_process_group()
@@ -1315,7 +1324,7 @@ def test_rccl_forced_gather_one_rank_both_modes():
     p.start()
     res = q.get(timeout=300)
     p.join(timeout=60)
-    assert res == {'rccl': True, 'work': True, 'side': True}, res
+    assert res == {'rccl': True, 'work': True, 'side': True, 'fallback': True}, res
 
 
 def test_rccl_allgather_two_ranks():
