@@ -14,7 +14,7 @@
  *  shapy_regressor_affine_f32
  *      IterativeRegression.forward / MLP.forward
  *      (regressor/human_shape/models/common/networks.py:536-592, :392-400)
- *  shapy_smplx_pose_f32, shapy_smplx_skin_f32, shapy_smplx_joints_f32
+ *  shapy_smplx_pose_f32, shapy_smplx_skin_f32, shapy_smplx_joints_f32, shapy_smplx_forward_f32
  *      ContinuousRotReprDecoder.forward (models/common/pose_utils.py:138-153),
  *      batch_rodrigues (utils/rotation_utils.py:5-37), lbs() and batch_rigid_transform
  *      (models/body_models/lbs.py:99-196, :242-295), the landmark code (lbs.py:20-94),
@@ -288,6 +288,23 @@ int shapy_smplx_joints_f32(const ShapySmplxModel *model_host, const float *posed
                            const float *vertices, const int32_t *dyn_row, const float *camera,
                            float *joints_out, float *proj_out, float *cam_scale_out, int B,
                            int use_face_contour, void *stream);
+
+/* The whole SMPL-X layer (SMPLX.forward, models/body_models/body_models.py:628-767, on prepared
+ * inputs) in ONE call: shape blend GEMM(s), pose decode + joint regression + kinematic chain, pose
+ * blend GEMM, skinning, landmarks (+ weak-perspective projection when `camera` is given) -- the
+ * launches of the entry points above, enqueued back to back.  coeffs_shape: the coefficients with the
+ * expression part zeroed (then v_shaped receives the shape-only vertices), or NULL (v_shaped_full IS
+ * v_shaped; v_shaped may be NULL).  shape_only: stop after the shape GEMM(s) (SMPL.forward_shape).
+ * Buffers: v_shaped_full, v_shaped, v_posed, vertices [B,V,3]; rot [B,J,3,3]; pose_feat [B,Ppad];
+ * A [B,J,12]; posed_joints [B,J,3]; dyn_row [B] int32; joints_out [B,n_out,3]; proj_out [B,n_out,2]
+ * and cam_scale_out [B,1] or NULL. */
+int shapy_smplx_forward_f32(const ShapySmplxModel *model_host, const float *pose, int pose_type,
+                            int n_pose, const float *coeffs, const float *coeffs_shape,
+                            const float *camera, float *v_shaped_full, float *v_shaped, float *rot,
+                            float *pose_feat, float *A, float *posed_joints, int32_t *dyn_row,
+                            float *v_posed, float *vertices, float *joints_out, float *proj_out,
+                            float *cam_scale_out, int B, int use_face_contour, int shape_only,
+                            void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Mesh-mesh intersection (the reference's operator boundary)

@@ -110,6 +110,9 @@ SIGNATURES = {
                                             ctypes.c_int, vp]),
     'shapy_smplx_joints_f32': (ctypes.c_int, [ctypes.POINTER(ShapySmplxModel), vp, vp, vp, vp, vp,
                                               vp, vp, ctypes.c_int, ctypes.c_int, vp]),
+    'shapy_smplx_forward_f32': (ctypes.c_int, [ctypes.POINTER(ShapySmplxModel), vp, ctypes.c_int,
+                                               ctypes.c_int] + [vp] * 15 +
+                                [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
     'shapy_b2a_polynomial_f32': (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, vp]),
     'shapy_crop_resize_normalize_u8': (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int,

@@ -539,6 +539,48 @@ extern "C" int shapy_smplx_joints_f32(const ShapySmplxModel *m, const float *pos
   return (int)hipGetLastError();
 }
 
+// The whole layer in ONE call: the five to six launches above, enqueued back to back from C (the
+// Python host spent ~40 us per call between its ctypes calls -- the layer's kernels take 85 us at
+// B = 64 and far less at B = 4, so the gaps were a third to two thirds of its wall time).
+static int smplx_gemm(const float *in, int B, int K, const float *wgt, int N, float *out,
+                      const float *bias, const float *res, hipStream_t s) {
+  ShapyConv d = {};
+  d.in = in; d.wgt = wgt; d.bias = bias; d.res = res; d.out = out;
+  d.B = B; d.Hi = d.Wi = d.Ho = d.Wo = 1; d.Cin = K; d.in_ld = K; d.Cout = N;
+  d.ksize = 1; d.stride = 1; d.pad = 0; d.out_ld = N; d.out_coff = 0; d.res_ld = N; d.res_coff = 0;
+  d.relu = 0; d.ups = 1; d.tile = 0; d.dtype = SHAPY_DTYPE_F32; d.wgt_wino = nullptr;
+  return conv2d(d, s);
+}
+
+extern "C" int shapy_smplx_forward_f32(const ShapySmplxModel *m, const float *pose, int pose_type,
+                                       int n_pose, const float *coeffs, const float *coeffs_shape,
+                                       const float *camera, float *v_shaped_full, float *v_shaped,
+                                       float *rot, float *pose_feat, float *A, float *posed_joints,
+                                       int32_t *dyn_row, float *v_posed, float *vertices,
+                                       float *joints_out, float *proj_out, float *cam_scale_out,
+                                       int B, int use_face_contour, int shape_only, void *stream) {
+  if (B <= 0) return SHAPY_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int N = m->V * 3;
+  int rc = smplx_gemm(coeffs, B, m->NBpad, m->shapedirs_t, N, v_shaped_full, m->v_template, nullptr, s);
+  if (rc) return rc;
+  if (coeffs_shape) {
+    if (!v_shaped) return SHAPY_EINVAL;
+    rc = smplx_gemm(coeffs_shape, B, m->NBpad, m->shapedirs_t, N, v_shaped, m->v_template, nullptr, s);
+    if (rc) return rc;
+  }
+  if (shape_only) return SHAPY_OK;
+  rc = shapy_smplx_pose_f32(m, pose, pose_type, n_pose, coeffs, rot, pose_feat, A, posed_joints,
+                            dyn_row, B, stream);
+  if (rc) return rc;
+  rc = smplx_gemm(pose_feat, B, m->Ppad, m->posedirs_t, N, v_posed, nullptr, v_shaped_full, s);
+  if (rc) return rc;
+  rc = shapy_smplx_skin_f32(m, A, v_posed, vertices, B, stream);
+  if (rc) return rc;
+  return shapy_smplx_joints_f32(m, posed_joints, vertices, dyn_row, camera, joints_out, proj_out,
+                                cam_scale_out, B, use_face_contour, stream);
+}
+
 extern "C" int shapy_pose_decode_f32(const float *pose, int pose_type, float *rot_out, int64_t n,
                                      void *stream) {
   if (n <= 0) return SHAPY_OK;

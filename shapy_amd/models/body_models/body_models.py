@@ -319,47 +319,54 @@ class SMPLX(VersionedWeights, nn.Module):
         V, J = dm['V'], dm['J']
         B, n_pose = coeffs.shape[0], pose.shape[1]
         f32 = dict(dtype=torch.float32, device=device)
-        N = V * 3
-        v_shaped_full = torch.empty(B, V, 3, **f32)
-        self._gemm(lib, stream, coeffs, dm['NBpad'], dm['tensors']['shapedirs_t'], N, v_shaped_full,
-                   bias=dm['tensors']['v_template'])
-        if coeffs_shape is None:
-            v_shaped = v_shaped_full
-        else:
-            v_shaped = torch.empty(B, V, 3, **f32)
-            self._gemm(lib, stream, coeffs_shape, dm['NBpad'], dm['tensors']['shapedirs_t'], N,
-                       v_shaped, bias=dm['tensors']['v_template'])
+        # ONE allocation for everything the layer writes and ONE C call for all its launches
+        # (shapy_smplx_forward_f32): between ctypes calls the host used to lose ~40 us per layer
+        n_out = J + m.n_static_lmk + (m.n_dyn_lmk if self.use_face_contour else 0)
+        # the fused projection is only valid when nothing edits the joints afterwards
+        fuse_cam = (camera is not None and not self.use_joint_regressor and transl is None
+                    and not _shape_only)
+        sizes = [('v_shaped_full', (B, V, 3)), ('v_shaped', (B, V, 3) if coeffs_shape is not None else None)]
+        if not _shape_only:
+            sizes += [('rot', (B, J, 3, 3)), ('pf', (B, dm['Ppad'])), ('A', (B, J, 12)),
+                      ('posed', (B, J, 3)), ('dyn_row', (B,)), ('v_posed', (B, V, 3)),
+                      ('vertices', (B, V, 3)), ('joints', (B, n_out, 3)),
+                      ('proj', (B, n_out, 2) if fuse_cam else None),
+                      ('scale', (B, 1) if fuse_cam else None)]
+        total, offs = 0, {}
+        for name, shp in sizes:
+            if shp is None:
+                continue
+            n = 1
+            for q in shp:
+                n *= q
+            offs[name] = (total, n, shp)
+            total += (n + 3) // 4 * 4                       # 16-byte aligned slices
+        arena = torch.empty(total, **f32)
+
+        def view(name):
+            if name not in offs:
+                return None
+            o, n, shp = offs[name]
+            return arena[o:o + n].view(shp)
+        bufs = {name: view(name) for name, _ in sizes}
+        dyn_row = bufs.get('dyn_row')
+        if dyn_row is not None:
+            dyn_row = dyn_row.view(torch.int32)
+        p = _lib.ptr
+        _lib.check(lib.shapy_smplx_forward_f32(
+            ctypes_byref(m), p(pose), _lib.POSE_ROTMAT, n_pose, p(coeffs), p(coeffs_shape), p(camera) if fuse_cam else None,
+            p(bufs['v_shaped_full']), p(bufs.get('v_shaped')), p(bufs.get('rot')), p(bufs.get('pf')),
+            p(bufs.get('A')), p(bufs.get('posed')), p(dyn_row), p(bufs.get('v_posed')),
+            p(bufs.get('vertices')), p(bufs.get('joints')), p(bufs.get('proj')), p(bufs.get('scale')),
+            B, int(self.use_face_contour), int(_shape_only), stream), 'shapy_smplx_forward_f32')
+        v_shaped_full = bufs['v_shaped_full']
+        v_shaped = v_shaped_full if coeffs_shape is None else bufs['v_shaped']
         output = defaultdict(lambda: None, faces=self.faces)
         if return_shaped:
             output['v_shaped'] = v_shaped
         if _shape_only:
             return output
-
-        rot = torch.empty(B, J, 3, 3, **f32)
-        pf = torch.empty(B, dm['Ppad'], **f32)
-        A = torch.empty(B, J, 12, **f32)
-        posed = torch.empty(B, J, 3, **f32)
-        dyn_row = torch.empty(B, dtype=torch.int32, device=device)
-        _lib.check(lib.shapy_smplx_pose_f32(
-            ctypes_byref(m), _lib.ptr(pose), _lib.POSE_ROTMAT, n_pose, _lib.ptr(coeffs),
-            _lib.ptr(rot), _lib.ptr(pf), _lib.ptr(A), _lib.ptr(posed), _lib.ptr(dyn_row), B,
-            stream), 'shapy_smplx_pose_f32')
-        v_posed = torch.empty(B, V, 3, **f32)
-        self._gemm(lib, stream, pf, dm['Ppad'], dm['tensors']['posedirs_t'], N, v_posed,
-                   res=v_shaped_full)
-        vertices = torch.empty(B, V, 3, **f32)
-        _lib.check(lib.shapy_smplx_skin_f32(ctypes_byref(m), _lib.ptr(A), _lib.ptr(v_posed),
-                                            _lib.ptr(vertices), B, stream), 'shapy_smplx_skin_f32')
-        n_out = J + m.n_static_lmk + (m.n_dyn_lmk if self.use_face_contour else 0)
-        joints = torch.empty(B, n_out, 3, **f32)
-        # the fused projection is only valid when nothing edits the joints afterwards
-        fuse_cam = camera is not None and not self.use_joint_regressor and transl is None
-        proj = torch.empty(B, n_out, 2, **f32) if fuse_cam else None
-        scale = torch.empty(B, 1, **f32) if fuse_cam else None
-        _lib.check(lib.shapy_smplx_joints_f32(
-            ctypes_byref(m), _lib.ptr(posed), _lib.ptr(vertices), _lib.ptr(dyn_row),
-            _lib.ptr(camera) if fuse_cam else None, _lib.ptr(joints), _lib.ptr(proj),
-            _lib.ptr(scale), B, int(self.use_face_contour), stream), 'shapy_smplx_joints_f32')
+        vertices, joints, proj, scale = bufs['vertices'], bufs['joints'], bufs.get('proj'), bufs.get('scale')
 
         if self.use_joint_regressor:
             Jn = self.extra_joint_regressor.shape[0]

@@ -55,7 +55,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.shapy_abi_version() == 5
+    assert lib.shapy_abi_version() == 6
     assert lib.shapy_build_arch() == b'gfx950'
     # struct layouts agree with the C header (sizeof through a tiny C program)
     src = '#include <stdio.h>\n#include "shapy_hip.h"\nint main(){printf("%zu %zu %zu", ' \
