@@ -642,7 +642,7 @@ def run_regressor(args, rank, world, local_rank):
                                  else '/tmp/shapy_synth_models')
         net.backbone.multi_stream = not args.single_stream
         net.backbone.compute_dtype = args.dtype
-        net.backbone.use_graph = {'auto': 'auto', 'on': True, 'off': False}[args.graph]
+        net.backbone.use_graph = {'auto': 'auto', 'on': True, 'off': False, 'explicit': 'explicit'}[args.graph]
         if args.algo:
             net.backbone.conv_algo = args.algo
         if args.wino4_min_hw:
@@ -809,9 +809,10 @@ def run_regressor(args, rank, world, local_rank):
                    'global_batch': world * B, 'parallelism': f'dp{world}',
                    'multi_stream': not args.single_stream, 'conv_algo': algo,
                    'd2h_betas_in_timed_region': True,
-                   'hip_graph': bool(net.backbone.use_graph is True or
-                                     (net.backbone.use_graph == 'auto' and
-                                      B <= net.backbone.graph_max_batch))},
+                   'hip_graph': ('explicit' if net.backbone.use_graph == 'explicit' else
+                                 bool(net.backbone.use_graph is True or
+                                      (net.backbone.use_graph == 'auto' and
+                                       B <= net.backbone.graph_max_batch)))},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak,
                      'unit': 'TFLOP/s', 'frac': achieved / peak,
                      'traffic': traffic['bytes_fetch_x2_corrected'] if traffic else None,
@@ -871,9 +872,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true',
                     help='skip the CPU oracle (cpu_baseline and parity fields)')
     ap.add_argument('--single-stream', action='store_true')
-    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off', 'explicit'],
                     help='replay the backbone as one hipGraph (auto: never since round 3 -- the eager '
-                         'event-driven forward is faster at every batch size; on: always)')
+                         'event-driven forward is faster at every batch size; on: the captured barrier plan; '
+                         'explicit: the event-driven plan as a hand-built graph)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f32x6', 'bf16'],
                     help='f32 = BASELINE configs[1] (headline) on the f32 matrix-core path; '
                          'f32x6 = same float32 tensors, products from the exact 3-way bf16 split '

@@ -186,6 +186,14 @@ int shapy_hrnet_graph_create(const ShapyOp *ops_host, int n_ops, const void *wei
                              const float *input_nchw, void *workspace,
                              int64_t ws_elems_per_image, float *features_out, int B, int H,
                              int W, int multi_stream, int dtype, void **graph_out);
+/* The op list's EVENT-DRIVEN form (sig / wait, lanes, barriers) as an explicitly built hipGraph:
+ * kernel nodes read back from a single-stream capture, edges = the executor's ordering rules.  No
+ * multi-stream capture is involved (which crashes in graph creation on ROCm 7.2 for this plan).
+ * Launch / destroy with shapy_hrnet_graph_launch / _destroy. */
+int shapy_hrnet_graph_create_explicit(const ShapyOp *ops_host, int n_ops, const void *weights,
+                                      const float *input_nchw, void *workspace,
+                                      int64_t ws_elems_per_image, float *features_out, int B, int H,
+                                      int W, int dtype, void **graph_out);
 int shapy_hrnet_graph_launch(void *graph, void *stream);
 int shapy_hrnet_graph_destroy(void *graph);
 /* dtype = SHAPY_DTYPE_F32: weights / workspace are float32 (the parity path);

@@ -91,6 +91,9 @@ SIGNATURES = {
                                                 vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_void_p)]),
+    'shapy_hrnet_graph_create_explicit': (ctypes.c_int, [ctypes.POINTER(ShapyOp), ctypes.c_int, vp, vp, vp,
+                                                         ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int,
+                                                         ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]),
     'shapy_hrnet_graph_launch': (ctypes.c_int, [vp, vp]),
     'shapy_hrnet_graph_destroy': (ctypes.c_int, [vp]),
     'shapy_regressor_affine_f32': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int,

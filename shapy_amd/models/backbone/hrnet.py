@@ -454,8 +454,9 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.multi_stream = True
         self.tile_overrides = {}
         self.tile_flags = 0          # OR-ed into every conv's tile id (tuning knobs)
-        #: replay the forward as one hipGraph (csrc/capi.hip) instead of ~330 launches: True,
-        #: False, or 'auto' = for batches up to graph_max_batch
+        #: replay the forward as one hipGraph (csrc/capi.hip) instead of ~330 launches: True (the
+        #: captured barrier plan), 'explicit' (the event-driven plan as a hand-built graph:
+        #: shapy_hrnet_graph_create_explicit), False, or 'auto' = True for batches up to graph_max_batch
         self.use_graph = 'auto'
         #: round 3: 0 = 'auto' never captures -- with the event-driven plan and lane priorities the
         #: eager forward is faster than the replay at every batch size (B = 1: 5.5 vs 6.3 ms, B = 8:
@@ -922,7 +923,9 @@ class HighResolutionNet(VersionedWeights, nn.Module):
     def _compile(self, H, W, device, graph=False):
         # event-driven plan: eager multi-stream forwards only (capturing it into a hipGraph segfaults
         # inside graph creation on ROCm 7.2; the captured plan keeps the barrier form)
-        self._dag_eff = bool(self.dag and self.multi_stream and not graph)
+        # (graph == 'explicit': the event-driven plan again, as a hand-built hipGraph without any
+        # multi-stream capture -- shapy_hrnet_graph_create_explicit)
+        self._dag_eff = bool(self.dag and self.multi_stream and (not graph or graph == 'explicit'))
         if self.compute_dtype not in ('f32', 'f32x6', 'bf16'):
             raise ValueError(f'unknown compute_dtype {self.compute_dtype!r}')
         bf16 = self.compute_dtype == 'bf16'
@@ -1076,12 +1079,13 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 run(one)
         return out
 
-    def _forward_graph(self, lib, eng, x):
+    def _forward_graph(self, lib, eng, x, explicit=False):
         B, _, H, W = x.shape
-        key = (B, bool(self.multi_stream))
+        key = (B, bool(self.multi_stream), bool(explicit))
         g = eng['graphs'].get(key)
         if g is None:
-            g = eng['graphs'][key] = _CapturedForward(lib, eng, B, H, W, x.device, self.multi_stream)
+            g = eng['graphs'][key] = _CapturedForward(lib, eng, B, H, W, x.device, self.multi_stream,
+                                                      explicit=explicit)
         return g(x)
 
     def forward(self, x):
@@ -1099,6 +1103,10 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             raise ValueError('HRNet input height/width must be multiples of 32')
         x = x.contiguous().float()
         use_graph = self.use_graph is True or (self.use_graph == 'auto' and B <= self.graph_max_batch)
+        if self.use_graph == 'explicit' and self.multi_stream and self.dag:
+            use_graph = 'explicit'
+        elif self.use_graph == 'explicit':
+            use_graph = True          # single-stream / barrier plans: the captured graph
         self._n_forward += 1
         if self.wino_guard and self.compute_dtype == 'f32' and self.conv_algo in ('winograd', 'winograd4', 'auto'):
             stale = self._calibrated_ver != self._weights_version()
@@ -1120,7 +1128,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 self.calibrate(x[:min(B, 2)], graph=use_graph)     # only ever ADDS demotions
         eng = self._compile(H, W, x.device, graph=use_graph)
         if use_graph:
-            return {'concat': self._forward_graph(lib, eng, x)}
+            return {'concat': self._forward_graph(lib, eng, x, explicit=use_graph == 'explicit')}
         need = eng['ws_per_img'] * B * eng['esz']
         # one workspace per CALLER stream: forwards issued on different streams (several batches
         # in flight) must not share activations
@@ -1141,7 +1149,7 @@ class _CapturedForward:
     """One hipGraph of the whole backbone for a fixed batch size, with the buffers it has baked
     in (they must stay alive and in place as long as the graph exists)."""
 
-    def __init__(self, lib, eng, B, H, W, device, multi_stream):
+    def __init__(self, lib, eng, B, H, W, device, multi_stream, explicit=False):
         self.lib = lib
         self.x = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
         self.feat = torch.empty(B, eng['feat_dim'], dtype=torch.float32, device=device)
@@ -1150,11 +1158,17 @@ class _CapturedForward:
         self.handle = ctypes.c_void_p()
         # capture happens on a private stream inside the library; make the buffers visible to it
         torch.cuda.current_stream().synchronize()
-        rc = lib.shapy_hrnet_graph_create(eng['ops'], eng['n_ops'], _lib.ptr(self.weights),
-                                          _lib.ptr(self.x), _lib.ptr(self.ws), eng['ws_per_img'],
-                                          _lib.ptr(self.feat), B, H, W, int(multi_stream),
-                                          eng['dtype'], ctypes.byref(self.handle))
-        _lib.check(rc, 'shapy_hrnet_graph_create')
+        if explicit:
+            rc = lib.shapy_hrnet_graph_create_explicit(
+                eng['ops'], eng['n_ops'], _lib.ptr(self.weights), _lib.ptr(self.x), _lib.ptr(self.ws),
+                eng['ws_per_img'], _lib.ptr(self.feat), B, H, W, eng['dtype'], ctypes.byref(self.handle))
+            _lib.check(rc, 'shapy_hrnet_graph_create_explicit')
+        else:
+            rc = lib.shapy_hrnet_graph_create(eng['ops'], eng['n_ops'], _lib.ptr(self.weights),
+                                              _lib.ptr(self.x), _lib.ptr(self.ws), eng['ws_per_img'],
+                                              _lib.ptr(self.feat), B, H, W, int(multi_stream),
+                                              eng['dtype'], ctypes.byref(self.handle))
+            _lib.check(rc, 'shapy_hrnet_graph_create')
 
     def __call__(self, x):
         self.x.copy_(x)

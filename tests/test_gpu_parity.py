@@ -715,6 +715,32 @@ def test_hrnet_two_host_threads_on_two_streams_bit_identical(network):
         assert all(torch.equal(g, refs[i]) for g in outs[i])
 
 
+def test_hrnet_explicit_graph_of_the_event_driven_plan_equals_eager(network):
+    """use_graph = 'explicit': the event-driven plan as a hand-built hipGraph (kernel nodes read back
+    from a single-stream capture, edges = lane order + sig / wait slots + barrier joins; no multi-stream
+    capture) replays bit-identically to the eager four-stream forward of the SAME plan, several
+    replays in a row, at two batch sizes."""
+    from shapy_amd.models.backbone import hrnet as hrnet_mod
+    from shapy_amd.utils import synthetic as syn
+    bb = network.backbone
+    keep = bb.multi_stream, bb.use_graph, bb.dag
+    bb.multi_stream, bb.dag, bb.conv_algo = True, True, hrnet_mod.DEFAULT_CONV_ALGO
+    try:
+        for B, size in ((1, 224), (3, 96)):
+            x = torch.from_numpy(syn.synthetic_images(B, size, 31)).cuda()
+            bb.use_graph = False
+            with torch.no_grad():
+                ref = bb(x)['concat'].clone()
+            bb.use_graph = 'explicit'
+            with torch.no_grad():
+                got = [bb(x)['concat'].clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            assert all(torch.equal(g, ref) for g in got), (B, size)
+    finally:
+        bb.multi_stream, bb.use_graph, bb.dag = keep
+        bb.conv_algo = 'direct'
+
+
 def test_conv2d_group_c_abi_matches_single_launches():
     """shapy_conv2d_group through the C-ABI: groups of 1-4 layers incl. partly filled workgroups,
     a channel-offset epilogue, Cout = 144 (the generic XCD split), more tasks than workgroup slots;
