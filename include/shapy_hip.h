@@ -297,6 +297,16 @@ int shapy_smplx_joints_f32(const ShapySmplxModel *model_host, const float *posed
                            float *joints_out, float *proj_out, float *cam_scale_out, int B,
                            int use_face_contour, void *stream);
 
+/* Argument glue of SMPLX.forward (body_models.py:660-700) in one launch: up to 7 pose parts of
+ * rotation matrices ([B, n_joints_host[k], 3, 3] device pointers in the HOST array parts_host; a NULL
+ * part is identity) concatenated into pose_out [B, sum n, 3, 3]; betas [B, nb] (+ expression [B, ne],
+ * NULL = none) into coeffs_out [B, NBpad] (zero padded) and, when coeffs_shape_out is given, the same
+ * row with the expression part zeroed. */
+int shapy_smplx_prepare_f32(const float *const *parts_host, const int32_t *n_joints_host, int n_parts,
+                            const float *betas, int nb, const float *expression, int ne, int NBpad,
+                            float *pose_out, float *coeffs_out, float *coeffs_shape_out, int B,
+                            void *stream);
+
 /* The whole SMPL-X layer (SMPLX.forward, models/body_models/body_models.py:628-767, on prepared
  * inputs) in ONE call: shape blend GEMM(s), pose decode + joint regression + kinematic chain, pose
  * blend GEMM, skinning, landmarks (+ weak-perspective projection when `camera` is given) -- the

@@ -1,6 +1,8 @@
 // Regressor head + SMPL-X kernels (everything between the backbone features and the posed
 // body).  One workgroup per body for the small per-body stages; the two blend-shape GEMMs run
 // on the MFMA conv/GEMM kernel (conv_igemm.hip) and are issued by the host.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace shapy {
@@ -398,6 +400,43 @@ __global__ void head_prepare_kernel(PrepK k) {
   }
 }
 
+// Argument glue of SMPLX.forward (body_models.py:660-700: the eye / cat of the pose parts, the zero
+// padded coefficient rows) in ONE launch: up to 7 pose parts (rotation matrices [B, n_k, 3, 3], NULL =
+// identity) -> pose [B, n_pose, 3, 3]; betas (+ expression) -> coeffs [B, NBpad] and, with an
+// expression, coeffs_shape (the same with the expression part zeroed).
+struct SmplxPrepK {
+  const float *part[7];
+  int n[7], first[7];            // joints of part k, index of its first joint
+  int n_parts, n_pose, B, nb, ne, NBpad;
+  const float *betas, *expr;
+  float *pose, *coeffs, *coeffs_shape;
+};
+
+__global__ void smplx_prepare_kernel(SmplxPrepK k) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n_rot = (long)k.B * k.n_pose * 9, n_co = (long)k.B * k.NBpad;
+  if (i < n_rot) {
+    const int q = (int)(i % 9);
+    const long bj = i / 9;
+    const int j = (int)(bj % k.n_pose);
+    const long b = bj / k.n_pose;
+    float v = (q == 0 || q == 4 || q == 8) ? 1.f : 0.f;
+#pragma unroll
+    for (int p = 0; p < 7; ++p)
+      if (p < k.n_parts && k.part[p] && j >= k.first[p] && j < k.first[p] + k.n[p])
+        v = k.part[p][(b * k.n[p] + (j - k.first[p])) * 9 + q];
+    k.pose[i] = v;
+  } else if (i < n_rot + n_co) {
+    const long r = i - n_rot;
+    const int c = (int)(r % k.NBpad);
+    const long b = r / k.NBpad;
+    const float sh = (c < k.nb && k.betas) ? k.betas[b * k.nb + c] : 0.f;
+    const float ex = (c >= k.nb && c < k.nb + k.ne && k.expr) ? k.expr[b * k.ne + (c - k.nb)] : 0.f;
+    k.coeffs[r] = c < k.nb ? sh : ex;
+    if (k.coeffs_shape) k.coeffs_shape[r] = sh;
+  }
+}
+
 __global__ void weak_persp_kernel(const float *__restrict__ pts, const float *__restrict__ scale,
                                   const float *__restrict__ transl, float *__restrict__ out, int N,
                                   int scale_first, long total) {
@@ -543,12 +582,12 @@ extern "C" int shapy_smplx_joints_f32(const ShapySmplxModel *m, const float *pos
 // Python host spent ~40 us per call between its ctypes calls -- the layer's kernels take 85 us at
 // B = 64 and far less at B = 4, so the gaps were a third to two thirds of its wall time).
 static int smplx_gemm(const float *in, int B, int K, const float *wgt, int N, float *out,
-                      const float *bias, const float *res, hipStream_t s) {
+                      const float *bias, const float *res, hipStream_t s, int tile = 0) {
   ShapyConv d = {};
   d.in = in; d.wgt = wgt; d.bias = bias; d.res = res; d.out = out;
   d.B = B; d.Hi = d.Wi = d.Ho = d.Wo = 1; d.Cin = K; d.in_ld = K; d.Cout = N;
   d.ksize = 1; d.stride = 1; d.pad = 0; d.out_ld = N; d.out_coff = 0; d.res_ld = N; d.res_coff = 0;
-  d.relu = 0; d.ups = 1; d.tile = 0; d.dtype = SHAPY_DTYPE_F32; d.wgt_wino = nullptr;
+  d.relu = 0; d.ups = 1; d.tile = tile; d.dtype = SHAPY_DTYPE_F32; d.wgt_wino = nullptr;
   return conv2d(d, s);
 }
 
@@ -573,7 +612,10 @@ extern "C" int shapy_smplx_forward_f32(const ShapySmplxModel *m, const float *po
   rc = shapy_smplx_pose_f32(m, pose, pose_type, n_pose, coeffs, rot, pose_feat, A, posed_joints,
                             dyn_row, B, stream);
   if (rc) return rc;
-  rc = smplx_gemm(pose_feat, B, m->Ppad, m->posedirs_t, N, v_posed, nullptr, v_shaped_full, s);
+  // (M = batch is skinny: every workgroup walks its 31 K chunks of posedirs alone -- three chunks of
+  // loads in flight, tile flag 0x40000, instead of one; SHAPY_SMPLX_PD1=1 restores one for A/B runs)
+  static const int pd_flag = getenv("SHAPY_SMPLX_PD1") ? 0 : 0x40000;
+  rc = smplx_gemm(pose_feat, B, m->Ppad, m->posedirs_t, N, v_posed, nullptr, v_shaped_full, s, pd_flag);
   if (rc) return rc;
   rc = shapy_smplx_skin_f32(m, A, v_posed, vertices, B, stream);
   if (rc) return rc;
@@ -606,6 +648,30 @@ extern "C" int shapy_head_prepare_f32(const float *params, int S, int B, int P, 
   k.betas_off = betas_off; k.n_betas = n_betas; k.NBpad = NBpad; k.cam_off = cam_off;
   const long total = (long)S * B * n_joints + (long)B * NBpad + (cam_out ? (long)B * 3 : 0);
   hipLaunchKernelGGL(head_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, k);
+  return (int)hipGetLastError();
+}
+
+extern "C" int shapy_smplx_prepare_f32(const float *const *parts_host, const int32_t *n_joints_host,
+                                       int n_parts, const float *betas, int nb, const float *expression,
+                                       int ne, int NBpad, float *pose_out, float *coeffs_out,
+                                       float *coeffs_shape_out, int B, void *stream) {
+  if (B <= 0) return SHAPY_OK;
+  if (n_parts < 0 || n_parts > 7 || nb < 0 || ne < 0 || nb + ne > NBpad || !coeffs_out ||
+      (n_parts > 0 && (!parts_host || !n_joints_host || !pose_out)))
+    return SHAPY_EINVAL;
+  SmplxPrepK k = {};
+  int first = 0;
+  for (int p = 0; p < n_parts; ++p) {
+    if (n_joints_host[p] < 0) return SHAPY_EINVAL;
+    k.part[p] = parts_host[p]; k.n[p] = n_joints_host[p]; k.first[p] = first;
+    first += n_joints_host[p];
+  }
+  k.n_parts = n_parts; k.n_pose = first; k.B = B; k.nb = nb; k.ne = ne; k.NBpad = NBpad;
+  k.betas = betas; k.expr = expression; k.pose = pose_out; k.coeffs = coeffs_out;
+  k.coeffs_shape = coeffs_shape_out;
+  const long total = (long)B * first * 9 + (long)B * NBpad;
+  hipLaunchKernelGGL(smplx_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, k);
   return (int)hipGetLastError();
 }

@@ -276,20 +276,44 @@ class SMPLX(VersionedWeights, nn.Module):
         last = max([i for i, (p, _) in enumerate(parts) if p is not None], default=-1)
         given = parts[:last + 1]
         n_pose = sum(n for _, n in given)
-        if n_pose:
-            full_pose = torch.cat([eye(n) if p is None else p.reshape(-1, n, 3, 3).to(**f32)
-                                   for p, n in given], dim=1).contiguous()
-        else:
-            full_pose = torch.empty(B, 0, 3, 3, **f32)
-        if betas is None:
-            betas = torch.zeros([B, self.num_betas], **f32)
-        coeffs = torch.zeros(B, dm['NBpad'], **f32)
-        coeffs[:, :dm['nb']] = betas
-        coeffs_shape = None
-        if expression is not None:
-            coeffs[:, dm['nb']:dm['NB']] = expression
-            coeffs_shape = coeffs.clone()
-            coeffs_shape[:, dm['nb']:] = 0
+        # one launch for the whole argument glue (shapy_smplx_prepare_f32) instead of eye / cat /
+        # zeros / slice assignments / clone: 8-10 tiny torch kernels per call
+        lib = _lib.load()
+        keep = []
+
+        def dev_f32(t, shape):
+            t = t.reshape(shape)
+            if t.shape[0] != B:
+                if t.shape[0] != 1:
+                    raise ValueError(f'batch size mismatch: {t.shape[0]} vs {B}')
+                t = t.expand(B, *t.shape[1:])
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
+                t = t.to(**f32).contiguous()
+            keep.append(t)
+            return t
+        ptrs = (ctypes_vp() * 7)()
+        cnts = (ctypes_i32() * 7)()
+        for q, (p_, n) in enumerate(given):
+            cnts[q] = n
+            ptrs[q] = None if p_ is None else dev_f32(p_, (-1, n, 3, 3)).data_ptr()
+        NBpad, nb, ne = dm['NBpad'], dm['nb'], dm['ne']
+        has_expr = expression is not None
+        n_arena = B * n_pose * 9 + B * NBpad * (2 if has_expr else 1)
+        arena = torch.empty(n_arena, **f32)
+        full_pose = arena[:B * n_pose * 9].view(B, n_pose, 3, 3)
+        o = B * n_pose * 9
+        coeffs = arena[o:o + B * NBpad].view(B, NBpad)
+        coeffs_shape = arena[o + B * NBpad:].view(B, NBpad) if has_expr else None
+        betas_t = None if betas is None else dev_f32(betas, (B, -1))
+        if betas_t is not None and betas_t.shape[1] != nb:
+            raise ValueError(f'betas: expected {nb} coefficients, got {betas_t.shape[1]}')
+        expr_t = dev_f32(expression, (B, -1)) if has_expr else None
+        if has_expr and expr_t.shape[1] != ne:
+            raise ValueError(f'expression: expected {ne} coefficients, got {expr_t.shape[1]}')
+        _lib.check(lib.shapy_smplx_prepare_f32(
+            ptrs, cnts, len(given), _lib.ptr(betas_t), nb, _lib.ptr(expr_t), ne if has_expr else 0, NBpad,
+            _lib.ptr(full_pose) if n_pose else None, _lib.ptr(coeffs), _lib.ptr(coeffs_shape), B,
+            _lib.current_stream()), 'shapy_smplx_prepare_f32')
         out = self.forward_prepared(full_pose, coeffs, coeffs_shape=coeffs_shape, transl=transl,
                                     get_skin=get_skin, return_shaped=return_shaped,
                                     _shape_only=_shape_only)
@@ -395,3 +419,13 @@ class SMPLX(VersionedWeights, nn.Module):
 def ctypes_byref(x):
     import ctypes
     return ctypes.byref(x)
+
+
+def ctypes_vp():
+    import ctypes
+    return ctypes.c_void_p
+
+
+def ctypes_i32():
+    import ctypes
+    return ctypes.c_int32
