@@ -384,7 +384,7 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
       if (d.dtype != SHAPY_DTYPE_F32 || !conv_wino_eligible(k)) return SHAPY_EINVAL;
       return conv2d_wino4(k, s);
     }
-    if (d.dtype != SHAPY_DTYPE_F32 || k.Cout % 48) return SHAPY_EINVAL;
+    if (d.dtype != SHAPY_DTYPE_F32 || (k.Cout % 48 && k.Cout % 64)) return SHAPY_EINVAL;
     // tensors beyond the kernel's 1 GiB offset scheme (B > 334 at 224x224) or with rows that are
     // not 16-byte aligned: the direct kernel on
     // the untransformed weights, which every layer carries -- slower, same convolution

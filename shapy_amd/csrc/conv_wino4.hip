@@ -12,7 +12,7 @@
 //
 // GEMM view: 36 independent GEMMs (Winograd position p = 6 i + j), [tiles x Cin] x [Cin x Cout].
 // One 256-thread workgroup = 16 consecutive tiles (4x4 output pixels each, row-major over
-// (b, ty, tx)) x N = 48 or 64 output channels:
+// (b, ty, tx)) x N = 48 (three multiplying waves) or 64 (four) output channels:
 //   * staging, ONE wave (wave 3): lane (tile, 4 channels) loads the 6 x 6 patch of its tile as 36
 //     16-byte loads (out-of-image taps zeroed by the buffer bounds check), applies B^T d B entirely
 //     in registers -- no cross-lane exchange -- and writes V[p][tile][16 ch] to LDS (36 KB per
@@ -54,9 +54,13 @@ namespace shapy {
 // chunk loop is unrolled: hipcc's s_waitcnt bookkeeping is exact only in straight-line code -- at
 // the header of a real loop it drains vmcnt(0), i.e. waits for the whole filter ring once per
 // chunk (an L2 latency of idle matrix cores every 144 MFMAs).
-template <int KC>
-__global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
-  constexpr int N = 48;
+// NW = multiplying waves: 3 (N = 48 output channels per workgroup, 256 threads, two workgroups per CU)
+// or 4 (N = 64, 320 threads: layers whose Cout is a multiple of 64 but not of 48 -- layer1's 64 -> 64
+// and the head's 512 -> 512; five waves of 256 registers leave room for ONE workgroup per CU, all four
+// SIMDs multiply and the staging wave shares one of them).
+template <int KC, int NW = 3>
+__global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
+  constexpr int N = 16 * NW;
   constexpr int PSTR = 1024;                          // bytes per position: 16 tiles x 16 ch f32
   constexpr int LDS_V = 36 * PSTR;
   constexpr int R = WINO4_RING;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(ConvK p) {
   const int T = p.wino_tiles;
   const int CC = p.Cin >> 4;
 
-  if (wave == 3) {
+  if (wave == NW) {
     // =========================== staging wave ===========================
     // lane (tile, c4): the 6 x 6 patch of one tile for 4 channels of the current 16-channel
     // chunk: 36 buffer_load_dwordx4 (144 registers -- this wave holds no accumulators).  Zero
@@ -288,7 +292,7 @@ bool conv_wino4_fits(const ConvK &k) {
   // offsets in multiples of 4 floats, 16-byte-aligned tensors -- every HRNet tensor; anything else
   // takes another kernel
   const bool al = k.vec4 != 0;
-  return al && k.Cout % 48 == 0 && k.in_bytes <= lim && 4ull * k.M * k.out_ld <= lim &&
+  return al && (k.Cout % 48 == 0 || k.Cout % 64 == 0) && k.in_bytes <= lim && 4ull * k.M * k.out_ld <= lim &&
          (!k.res || 4ull * k.M * k.res_ld <= lim) && 144ull * k.Cin * k.Cout < 0x7fffffffull;
 }
 
@@ -298,14 +302,22 @@ int conv2d_wino4(ConvK k, hipStream_t s) {
   const int B = k.M / (k.Ho * k.Wo);
   k.wino_tiles = B * ((k.Hi + 3) / 4) * ((k.Wi + 3) / 4);
   k.wgt2_bytes = (unsigned)(144ull * k.Cin * k.Cout);          // 36 positions x f32
-  k.nbx = k.Cout / 48;
+  const bool n64 = k.Cout % 48 != 0;                           // (conv_wino4_fits: then Cout % 64 == 0)
+  k.nbx = k.Cout / (n64 ? 64 : 48);
   k.nby = (k.wino_tiles + 15) / 16;
 #ifdef SHAPY_WINO_TIMING
   k.dbg = getenv("SHAPY_WINO_DBG") ? atoi(getenv("SHAPY_WINO_DBG")) : 0;
 #endif
   // transformed filters larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
   if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt2_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
-  const dim3 grid(k.nbx * k.nby), blk(256);
+  const dim3 grid(k.nbx * k.nby), blk(n64 ? 320 : 256);
+  if (n64) {
+    if (k.Cin == 64)
+      hipLaunchKernelGGL((conv_wino4_kernel<4, 4>), grid, blk, 0, s, k);
+    else
+      hipLaunchKernelGGL((conv_wino4_kernel<0, 4>), grid, blk, 0, s, k);
+    return (int)hipGetLastError();
+  }
   if (k.Cin == 48)
     hipLaunchKernelGGL(conv_wino4_kernel<3>, grid, blk, 0, s, k);
   else if (k.Cin == 96)

@@ -396,7 +396,8 @@ int conv2d_wino4_group(const ConvK *ks, int n, hipStream_t s) {
   long tasks = 0;
   for (int i = 0; i < n; ++i) {
     const ConvK &k = ks[i];
-    if (!k.wgt2 || !conv_wino_eligible(k) || !conv_wino4_fits(k) || k.Cout / 48 > 255) return SHAPY_EINVAL;
+    if (!k.wgt2 || !conv_wino_eligible(k) || !conv_wino4_fits(k) || k.Cout % 48 || k.Cout / 48 > 255)
+      return SHAPY_EINVAL;                       // (the persistent kernel has the 48-channel tiling only)
     W4Conv &c = G.c[i];
     c.in = k.in; c.wgt2 = k.wgt2; c.res = k.res; c.bias = k.bias; c.out = k.out;
     c.Hi = k.Hi; c.Wi = k.Wi; c.Cin = k.Cin; c.Cout = k.Cout; c.in_ld = k.in_ld;

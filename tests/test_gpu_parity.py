@@ -205,6 +205,10 @@ WINO4_CASES = [
     (1, 7, 7, 384, 384, True, True),       # N-slab order (transformed filters > 2 MB)
     (5, 4, 4, 16, 48, False, False),       # one tile per image, 5 of 16 tiles live
     (1, 3, 3, 16, 48, True, False),        # smaller than one tile
+    (2, 12, 20, 64, 64, True, True),       # 64-channel N tile: four multiplying waves, unrolled 4 chunks
+    (1, 7, 7, 32, 128, True, False),       # ... two N tiles, generic chunk loop
+    (2, 56, 56, 64, 64, False, True),      # layer1's 3x3 class
+    (1, 7, 7, 512, 512, False, True),      # the head's 3x3 class (N-slab order)
 ]
 
 
@@ -260,8 +264,8 @@ def test_conv_winograd4_concat_offset_and_refusals(lib):
     ref = _conv_ref(x, w, b, before[..., 16:64], True, 1, 1)
     assert (big[..., 16:64].cpu().double() - ref).abs().max().item() < 3e-5
     assert torch.equal(big[..., :16], before[..., :16]) and torch.equal(big[..., 64:], before[..., 64:])
-    # Cout = 64 has no 48-channel N tiling; stride 2 is not a Winograd layer
-    for cout, stride in ((64, 1), (48, 2)):
+    # Cout = 80 has neither a 48- nor a 64-channel N tiling; stride 2 is not a Winograd layer
+    for cout, stride in ((80, 1), (48, 2)):
         w2 = torch.randn(cout, 3, 3, 32, generator=g).cuda()
         d = _lib.ShapyConv()
         out = torch.empty(2, 10, 10, cout, device='cuda')

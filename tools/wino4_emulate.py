@@ -53,13 +53,14 @@ def emulate_workgroup(x, u, bias, res, relu, out, wg_m, wg_n, out_ld, out_coff, 
     TW, TH = (W + 3) // 4, (H + 3) // 4
     T = B * TH * TW
     CC = Cin // 16
-    m_blk, n_blk = wg_m * 16, wg_n * 48
+    NW = 3 if Cout % 48 == 0 else 4                      # multiplying waves: N = 48 or 64
+    m_blk, n_blk = wg_m * 16, wg_n * 16 * NW
     xin = x.reshape(-1)
     in_bytes = xin.size * 4
     uflat = u.reshape(-1)
     u_bytes = uflat.size * 4
     lds = np.zeros(2 * LDS_V // 4, f32)
-    acc = np.zeros((3, 64, 36, 4), np.float64)          # wave, lane, position, r
+    acc = np.zeros((NW, 64, 36, 4), np.float64)         # wave, lane, position, r
     pix_stride = in_ld * 4
     for cc in range(CC):
         # ---- staging wave: lane (tile_s, c4) ----
@@ -85,7 +86,7 @@ def emulate_workgroup(x, u, bias, res, relu, out, wg_m, wg_n, out_ld, out_coff, 
                     o = ((cc & 1) * LDS_V + st_off + (6 * i + j) * PSTR) // 4
                     lds[o:o + 4] = v[i]
         # ---- multiplying waves ----
-        for wave in range(3):
+        for wave in range(NW):
             n0 = n_blk + 16 * wave
             AF = np.zeros((36, 64, 4), f32)
             BF = np.zeros((36, 64, 4), f32)
@@ -112,7 +113,7 @@ def emulate_workgroup(x, u, bias, res, relu, out, wg_m, wg_n, out_ld, out_coff, 
     # ---- epilogue (conv_wino4.h): lane = tile m_blk + l15, channels n0 + 4 g .. + 3, 16-byte
     # residual loads / stores ----
     outf = out.reshape(-1)
-    for wave in range(3):
+    for wave in range(NW):
         n0 = n_blk + 16 * wave
         for lane in range(64):
             g, l15 = lane >> 4, lane & 15
@@ -169,7 +170,7 @@ def check(B, H, W, Cin, Cout, with_res, relu, coff=0, seed=0):
     out_ld = Cout + coff
     out = np.full((B, H, W, out_ld), np.nan, f32)
     TW, TH = (W + 3) // 4, (H + 3) // 4
-    nby, nbx = (B * TH * TW + 15) // 16, Cout // 48
+    nby, nbx = (B * TH * TW + 15) // 16, Cout // (48 if Cout % 48 == 0 else 64)
     for m in range(nby):
         for n in range(nbx):
             emulate_workgroup(
@@ -242,4 +243,6 @@ if __name__ == '__main__':
     check(2, 12, 20, 48, 48, True, True)                # 30 tiles: two workgroups, 3 chunks
     check(1, 7, 9, 32, 96, True, False)                 # partial edge tiles, two N tiles
     check(1, 14, 14, 16, 48, False, False, coff=16)     # concat-style channel offset
+    check(1, 9, 10, 32, 64, True, True)                 # 64-channel N tile: four multiplying waves
+    check(1, 6, 6, 16, 128, False, True)                # ... two of them
     print('emulation OK')
