@@ -35,7 +35,7 @@ BN_MOMENTUM = 0.1
 #: product defaults of HighResolutionNet.conv_algo / .wino4_min_hw (see there)
 DEFAULT_CONV_ALGO = 'winograd4'
 DEFAULT_WINO4_MIN_HW = 7
-DEFAULT_WINO4_N64 = '0'
+DEFAULT_WINO4_N64 = '1'
 
 
 # ------------------------------------------------------------------------------------------
@@ -486,10 +486,11 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.conv_algo = os.environ.get('SHAPY_CONV_ALGO', DEFAULT_CONV_ALGO)
         self.wino_min_hw = 14
         self.wino4_min_hw = int(os.environ.get('SHAPY_WINO4_MIN_HW', DEFAULT_WINO4_MIN_HW))
-        #: conv_algo='winograd4': layers whose Cout is a multiple of 64 but not of 48 (layer1's
-        #: 64 -> 64, the head's 512 -> 512) on the 64-channel variant of the F(4x4) kernel (four
-        #: multiplying waves, one workgroup per CU) instead of F(2x2)
+        #: conv_algo='winograd4': layers whose Cout is a multiple of 64 but not of 48 on the 64-channel
+        #: variant of the F(4x4) kernel (four multiplying waves, one workgroup per CU) instead of
+        #: F(2x2), on maps of at least wino4_n64_min_hw pixels a side (= layer1's four 64 -> 64 convs)
         self.wino4_n64 = os.environ.get('SHAPY_WINO4_N64', DEFAULT_WINO4_N64) == '1'
+        self.wino4_n64_min_hw = int(os.environ.get('SHAPY_WINO4_N64_MIN_HW', '28'))
 
         #: conv_algo='winograd4': the convs at the same depth of a HighResolutionModule's parallel
         #: branches as ONE persistent grouped launch (csrc/conv_wino4g.hip) instead of one launch
@@ -655,7 +656,10 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         return self.conv_algo in ('winograd', 'winograd4') or min(Hi, Wi) >= self.wino_min_hw
 
     def _use_wino4(self, ks, st, pad, cin, cout, Hi, Wi, ups):
-        if cout % 48 and not self.wino4_n64:          # 64-channel N tiles (four multiplying waves)
+        # 64-channel N tiles (four multiplying waves, one workgroup per CU): only where they beat
+        # F(2x2) -- 88 vs 104 us on layer1's 64 -> 64 @56x56, but 131 vs 100 us on the head's
+        # 512 -> 512 @7x7 (128 workgroups of 32 chunks; profiles/r04s_*)
+        if cout % 48 and not (self.wino4_n64 and min(Hi, Wi) >= self.wino4_n64_min_hw):
             return False
         return (self.conv_algo == 'winograd4' and min(Hi, Wi) >= self.wino4_min_hw
                 and winograd.eligible4(ks, st, pad, cin, cout, ups))
@@ -943,7 +947,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             self._engine_ver = ver
         key = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
                self.wino4_min_hw, self._group_on(), self._dag_eff, self.dag_aux, self.dag_no_barriers, self.dag_balance,
-               self.wino4_n64,
+               self.wino4_n64, self.wino4_n64_min_hw,
                tuple(sorted(self.layer_algo.items())),
                self.tile_flags, tuple(sorted(self.tile_overrides.items())))
         eng = self._engine.get(key)
