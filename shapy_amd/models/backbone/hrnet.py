@@ -35,7 +35,7 @@ BN_MOMENTUM = 0.1
 #: product defaults of HighResolutionNet.conv_algo / .wino4_min_hw (see there)
 DEFAULT_CONV_ALGO = 'winograd4'
 DEFAULT_WINO4_MIN_HW = 7
-DEFAULT_WINO4_N64 = '1'
+DEFAULT_WINO4_N64 = '0'
 
 
 # ------------------------------------------------------------------------------------------
@@ -488,7 +488,10 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.wino4_min_hw = int(os.environ.get('SHAPY_WINO4_MIN_HW', DEFAULT_WINO4_MIN_HW))
         #: conv_algo='winograd4': layers whose Cout is a multiple of 64 but not of 48 on the 64-channel
         #: variant of the F(4x4) kernel (four multiplying waves, one workgroup per CU) instead of
-        #: F(2x2), on maps of at least wino4_n64_min_hw pixels a side (= layer1's four 64 -> 64 convs)
+        #: F(2x2), on maps of at least wino4_n64_min_hw pixels a side (= layer1's four 64 -> 64 convs).
+        #: OFF by default: the kernel is 15 % faster on that class in isolation (88 vs 104 us) but the
+        #: forward does not move (5,091 vs 5,082 images/s, three interleaved runs each,
+        #: profiles/r04t_*), and on the head's 512 -> 512 @7x7 it loses (131 vs 100 us)
         self.wino4_n64 = os.environ.get('SHAPY_WINO4_N64', DEFAULT_WINO4_N64) == '1'
         self.wino4_n64_min_hw = int(os.environ.get('SHAPY_WINO4_N64_MIN_HW', '28'))
 

@@ -359,11 +359,20 @@ def test_winograd4_plan_filters_and_kernel_indexing(hrnet):
     count = lambda plan: (
         sum(1 for o in plan.ops if o['type'] == 0 and o['tile'] & _lib.TILE_WINO4),
         sum(1 for o in plan.ops if o.get('wino_off', -1) >= 0 and not o['tile'] & _lib.TILE_WINO4))
-    assert count(P28) == (133, 85)                      # 48 @56x56, 96 @28x28, transition1, layer1's 64 @56x56
-    assert count(P) == (189, 29)                        # + 192 @14x14; the 7x7 maps keep F(2x2)
+    assert count(P28) == (129, 89)                      # 48 @56x56, 96 @28x28, transition1
+    assert count(P) == (185, 33)                        # + 192 @14x14; the 7x7 maps keep F(2x2)
     w4 = [o for o in P.ops if o['type'] == 0 and o['tile'] & _lib.TILE_WINO4]
-    assert all(min(o['Hi'], o['Wi']) >= hrnet.wino4_min_hw and o['wino_off'] >= 0 and
-               (o['Cout'] % 48 == 0 or (o['Cout'] == 64 and o['Hi'] == 56)) for o in w4)
+    assert all(min(o['Hi'], o['Wi']) >= hrnet.wino4_min_hw and o['Cout'] % 48 == 0 and
+               o['wino_off'] >= 0 for o in w4)
+    # the 64-channel N tile (opt-in): layer1's four 64 -> 64 @56x56 convs join, the 7x7 head convs do not
+    hrnet.conv_algo, hrnet.wino4_n64 = 'winograd4', True
+    try:
+        P64 = hrnet._build_plan(224, 224)
+    finally:
+        hrnet.conv_algo, hrnet.wino4_n64 = 'winograd', False
+    assert count(P64) == (189, 29)
+    assert sorted(o['name'] for o in P64.ops if o['type'] == 0 and o['tile'] & _lib.TILE_WINO4
+                  and o['Cout'] % 48) == [f'layer1.{i}.conv2' for i in range(4)]
     assert not any(o['tile'] & _lib.TILE_WINO4 for o in hrnet._build_plan(224, 224).ops)
     hrnet.conv_algo, hrnet.wino4_min_hw = keep
     rng = np.random.default_rng(0)
