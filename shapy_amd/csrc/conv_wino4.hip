@@ -206,27 +206,15 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
   auto chunk = [&](int cc, bool more) {
     wino4_lds_barrier();                     // chunk cc is staged
     const char *Vb = lds + (cc & 1) * LDS_V + frag_off;
-#ifdef SHAPY_W4_AF3
-    // THREE V-fragment buffers: the pair loaded in iteration pp overwrites the registers the MFMAs of
-    // iteration pp - 4 read (two iterations = 16 MFMAs = 512 cycles earlier), and is used in pp + 2
-    u32x4 af[3][2];
-#define W4_NXT(c) (((c) + 1) % 3)
-#else
     u32x4 af[2][2];
-#define W4_NXT(c) ((c) ^ 1)
-#endif
     af[0][0] = *reinterpret_cast<const u32x4 *>(Vb + 0 * PSTR);
     af[0][1] = *reinterpret_cast<const u32x4 *>(Vb + 1 * PSTR);
 #pragma unroll
     for (int pp = 0; pp < 36; pp += 2) {
-#ifdef SHAPY_W4_AF3
-      const int cur = (pp >> 1) % 3;
-#else
       const int cur = (pp >> 1) & 1;
-#endif
       if (pp + 2 < 36) {
-        af[W4_NXT(cur)][0] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 2) * PSTR);
-        af[W4_NXT(cur)][1] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 3) * PSTR);
+        af[cur ^ 1][0] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 2) * PSTR);
+        af[cur ^ 1][1] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 3) * PSTR);
       }
 #ifdef SHAPY_W4_PIN_AF
       // the next pair's V fragments are REQUESTED before this pair's MFMAs (hipcc otherwise gives both
@@ -257,10 +245,6 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
         else bload((pp + e) % R, q - 36, cc + 1, more);
       }
       __builtin_amdgcn_sched_barrier(0);
-#if defined(SHAPY_W4_AF3) && defined(SHAPY_W4_AF_KEEP)
-      // keep the fragments the PREVIOUS iteration multiplied allocated through this iteration's MFMAs
-      if (pp >= 2) asm volatile("" ::"v"(af[(cur + 2) % 3][0]), "v"(af[(cur + 2) % 3][1]));
-#endif
     }
   };
   if constexpr (KC > 0) {
