@@ -223,26 +223,39 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
 #endif
       // two positions interleaved: consecutive MFMAs hit different accumulators (40-cycle
       // dependent latency vs a 32-cycle issue interval)
+      // A operand = filter fragment, B operand = V fragment: D[channel 4 g + r][tile l15]
+      // (conv_wino4.h: the epilogue wants four consecutive channels of one tile per lane).
+      // The two filter refills sit BETWEEN the MFMAs of the pair, each right behind an MFMA that has
+      // just been issued, so that the VMEM issue overlaps that MFMA's 32 cycles (behind the last MFMA
+      // of the pair they cost 5-8 % on the 12- / 24-chunk classes: profiles/r04v_*).  They refill
+      // the slots the PREVIOUS pair consumed (lead R - 2 positions); pinned, or the compiler sinks
+      // them to the end of the chunk.
+      auto refill_prev = [&](int e) {
+        if (W4_DBG(8)) return;
+        if (pp >= 2) {
+          const int q = pp - 2 + e + R;
+          if (q < 36) bload((pp - 2 + e) % R, q, cc, true);
+          else bload((pp - 2 + e) % R, q - 36, cc + 1, more);
+        } else if (cc > 0) {
+          // positions 34 / 35 of the previous chunk: the same slots for THIS chunk's positions.  (Not in
+          // the first chunk: the preloaded ring still holds its positions R - 2, R - 1 there -- even
+          // a dropped load would zero them.  cc is a constant in the unrolled instantiations.)
+          bload((34 + e) % R, 34 + e + R - 36, cc, true);
+        }
+      };
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         if (W4_DBG(4) && kk > 0) break;
-        // A operand = filter fragment, B operand = V fragment: D[channel 4 g + r][tile l15]
-        // (conv_wino4.h: the epilogue wants four consecutive channels of one tile per lane)
         acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(
             __uint_as_float(bring[pp % R][kk]), __uint_as_float(af[cur][0][kk]), acc[pp], 0, 0, 0);
+        if (kk == 0 || kk == 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          refill_prev(kk >> 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         acc[pp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
             __uint_as_float(bring[(pp + 1) % R][kk]), __uint_as_float(af[cur][1][kk]), acc[pp + 1],
             0, 0, 0);
-      }
-      // refill the two ring slots just consumed, R positions ahead (pinned here: the compiler
-      // otherwise sinks the loads to the end of the chunk)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int q = pp + e + R;
-        if (W4_DBG(8)) continue;
-        if (q < 36) bload((pp + e) % R, q, cc, true);
-        else bload((pp + e) % R, q - 36, cc + 1, more);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
