@@ -304,6 +304,15 @@ int conv2d_wino4(ConvK k, hipStream_t s) {
   k.nby = (k.wino_tiles + 15) / 16;
 #ifdef SHAPY_WINO_TIMING
   k.dbg = getenv("SHAPY_WINO_DBG") ? atoi(getenv("SHAPY_WINO_DBG")) : 0;
+  // occupancy experiment: unused dynamic LDS on top of the 72 KB, so that one workgroup fits a CU
+  const int dyn = getenv("SHAPY_WINO_DYN_LDS") ? atoi(getenv("SHAPY_WINO_DYN_LDS")) : 0;
+  if (dyn) {
+    (void)hipFuncSetAttribute((const void *)conv_wino4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipFuncSetAttribute((const void *)conv_wino4_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    (void)hipFuncSetAttribute((const void *)conv_wino4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+  }
+#else
+  const int dyn = 0;
 #endif
   // transformed filters larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
   if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt2_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
@@ -316,16 +325,16 @@ int conv2d_wino4(ConvK k, hipStream_t s) {
     return (int)hipGetLastError();
   }
   if (k.Cin == 48)
-    hipLaunchKernelGGL(conv_wino4_kernel<3>, grid, blk, 0, s, k);
+    hipLaunchKernelGGL(conv_wino4_kernel<3>, grid, blk, dyn, s, k);
   else if (k.Cin == 96)
-    hipLaunchKernelGGL(conv_wino4_kernel<6>, grid, blk, 0, s, k);
+    hipLaunchKernelGGL(conv_wino4_kernel<6>, grid, blk, dyn, s, k);
   else if (k.Cin == 192 && k.w4_unroll12)
     // A/B knob (tile flag 0x200000): bit-identical to the generic loop and no faster (40.9 vs
     // 41.3 us at B = 64, profiles/r02y_wino4_unroll12_192.txt) -- the vmcnt(0) drain at the
     // header of the generic loop is not what bounds the 192-channel class
-    hipLaunchKernelGGL(conv_wino4_kernel<12>, grid, blk, 0, s, k);
+    hipLaunchKernelGGL(conv_wino4_kernel<12>, grid, blk, dyn, s, k);
   else
-    hipLaunchKernelGGL(conv_wino4_kernel<0>, grid, blk, 0, s, k);
+    hipLaunchKernelGGL(conv_wino4_kernel<0>, grid, blk, dyn, s, k);
   return (int)hipGetLastError();
 }
 

@@ -37,70 +37,111 @@ __device__ __forceinline__ float load_elem(const unsigned short *p) {
 }
 
 template <typename OutT>
-__global__ __launch_bounds__(256) void stem_conv_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(256, 4) void stem_conv_kernel(const float *__restrict__ in,
                                                         const float *__restrict__ wgt,
                                                         const float *__restrict__ bias,
                                                         OutT *__restrict__ out, int B, int H, int W,
                                                         int Ho, int Wo, int out_ld) {
-  // 256 threads = 2 segments of 16 consecutive output pixels (Wo % 16 == 0: a segment never leaves
-  // its row) x 8 groups of 8 output channels.  Each segment first stages its input patch
-  // (3 channels x 3 rows x 33 columns, zero padding applied) in LDS with coalesced row reads;
-  // round 2 had every thread fetch its 27 taps from global memory, 8 lanes the same address and
-  // neighbouring pixels two floats apart: load-issue-bound at 172 us for B = 64 (a 60 us job by HBM
-  // traffic).  Same taps in the same order -> bit-identical results.
-  __shared__ float w[27 * 64];   // w[k][n], k = (kh*3+kw)*3 + c
-  __shared__ float patch[2][3][3][34];
+  // 256 threads = 8 segments of 16 consecutive output pixels (Wo % 16 == 0: a segment never leaves
+  // its row) x 4 pixel quads x 8 groups of 8 output channels: a thread owns 4 consecutive pixels x 8
+  // channels.  Each segment first stages its input patch (3 channels x 3 rows x 33 columns, zero
+  // padding applied) in LDS with coalesced row reads.
+  // History: round 2 had every thread fetch its 27 taps from global memory (load-issue-bound, 172 us
+  // at B = 64); round 3 staged the patch but a thread owned ONE pixel x 8 channels and read 36 bytes
+  // of LDS per 8 FMAs -- 249 KB of LDS reads per 32 pixels, LDS-bandwidth-bound at 107 us for a 50 us
+  // job by HBM traffic.  Four pixels per thread share every weight read (3.3x fewer LDS bytes per
+  // FMA).  Same taps in the same order (kh, kw, c) per output -> bit-identical results.
+  __shared__ __attribute__((aligned(16))) float w[27 * 64];   // w[k][n], k = (kh*3+kw)*3 + c
+  __shared__ __attribute__((aligned(16))) float patch[8][3][3][36];
   for (int i = threadIdx.x; i < 27 * 64; i += 256) {
     const int n = i & 63, k = i >> 6;
     w[i] = wgt[n * 27 + k];
   }
-  const int seg = threadIdx.x >> 7, ts = threadIdx.x & 127;
   const long npix = (long)B * Ho * Wo;
-  const long seg_pix0 = (long)blockIdx.x * 32 + seg * 16;
-  const bool seg_live = seg_pix0 < npix;
-  const int wo0 = (int)(seg_pix0 % Wo);
-  const long tq = seg_pix0 / Wo;
-  const int ho = (int)(tq % Ho);
-  const int b = (int)(tq / Ho);
-  if (seg_live) {
-    const float *inb = in + (long)b * 3 * H * W;
-    for (int idx = ts; idx < 3 * 3 * 33; idx += 128) {
-      const int c = idx / 99, r = (idx % 99) / 33, j = idx % 33;
-      const int hi = ho * 2 - 1 + r, wi = wo0 * 2 - 1 + j;
-      const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-      patch[seg][c][r][j] = ok ? inb[((long)c * H + hi) * W + wi] : 0.f;
+  {
+    // staging: 32 threads per segment
+    const int seg = threadIdx.x >> 5, ts = threadIdx.x & 31;
+    const long seg_pix0 = (long)blockIdx.x * 128 + seg * 16;
+    if (seg_pix0 < npix) {
+      const int wo0 = (int)(seg_pix0 % Wo);
+      const long tq = seg_pix0 / Wo;
+      const int ho = (int)(tq % Ho);
+      const int b = (int)(tq / Ho);
+      const float *inb = in + (long)b * 3 * H * W;
+      for (int idx = ts; idx < 3 * 3 * 33; idx += 32) {
+        const int c = idx / 99, r = (idx % 99) / 33, j = idx % 33;
+        const int hi = ho * 2 - 1 + r, wi = wo0 * 2 - 1 + j;
+        const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        patch[seg][c][r][j] = ok ? inb[((long)c * H + hi) * W + wi] : 0.f;
+      }
     }
   }
   __syncthreads();
-  if (!seg_live) return;
-  const int g = ts & 7, pl = ts >> 3;
-  const long pix = seg_pix0 + pl;
-  float acc[8];
+  const int g = threadIdx.x & 7, quad = threadIdx.x >> 3;
+  const int seg = quad >> 2, q = quad & 3;
+  const long pix0 = (long)blockIdx.x * 128 + seg * 16 + q * 4;
+  if (pix0 >= npix) return;                       // (whole segments: npix % 16 == 0)
+  // (packed FMAs: v_pk_fma_f32 does two IEEE fmas per lane and instruction -- the plain form is
+  // VALU-bound at 40 us for B = 64)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int px = 0; px < 4; ++px)
 #pragma unroll
+    for (int i = 0; i < 4; ++i) acc[px][i] = f32x2{0.f, 0.f};
+  // (kh stays a loop: fully unrolled, hipcc requests all 54 weight fragments first and spills)
+#pragma unroll 1
   for (int kh = 0; kh < 3; ++kh) {
+    // columns 8 q .. 8 q + 8 of the three channel rows: pixel px reads column 2 px + kw of them
+    float x[3][9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float *row = &patch[seg][c][kh][8 * q];
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(row);
+      const f32x4 hi = *reinterpret_cast<const f32x4 *>(row + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x[c][e] = lo[e];
+        x[c][4 + e] = hi[e];
+      }
+      x[c][8] = row[8];
+    }
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float x = patch[seg][c][kh][2 * pl + kw];
         const float *wk = w + ((kh * 3 + kw) * 3 + c) * 64 + g * 8;
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wk);
+        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wk + 4);
+        const f32x2 wp[4] = {f32x2{w0[0], w0[1]}, f32x2{w0[2], w0[3]}, f32x2{w1[0], w1[1]},
+                             f32x2{w1[2], w1[3]}};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = fmaf(x, wk[i], acc[i]);
+        for (int px = 0; px < 4; ++px) {
+          const float xs = x[c][2 * px + kw];
+          const f32x2 xv = f32x2{xs, xs};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[px][i] = __builtin_elementwise_fma(xv, wp[i], acc[px][i]);
+        }
       }
     }
   }
-  // the 8 channels of a thread as 16-byte stores (8 lanes = the pixel's whole 256-byte row)
-  OutT *o = out + pix * out_ld + g * 8;
-  float r[8];
+  // the 8 channels of a thread as 16-byte stores (8 lanes = a pixel's whole 256-byte row)
+  float bs[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r[i] = fmaxf(acc[i] + bias[g * 8 + i], 0.f);
-  if ((out_ld & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-    store_row8(o, r);
-  } else {
+  for (int i = 0; i < 8; ++i) bs[i] = bias[g * 8 + i];
+  const bool vec = (out_ld & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) store_elem(o + i, r[i]);
+  for (int px = 0; px < 4; ++px) {
+    OutT *o = out + (pix0 + px) * out_ld + g * 8;
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = fmaxf(acc[px][i >> 1][i & 1] + bs[i], 0.f);
+    if (vec) {
+      store_row8(o, r);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) store_elem(o + i, r[i]);
+    }
   }
 }
 
@@ -297,7 +338,7 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
       if (o.Cin != 3 || o.Cout != 64 || o.ksize != 3 || o.stride != 2 || o.Wo % 16) return SHAPY_EINVAL;
       const long npix = (long)B * o.Ho * o.Wo;
       // the stem's own weights stay float32 (wgt_off counts float32 elements for this op)
-      const dim3 grid((unsigned)((npix + 31) / 32));
+      const dim3 grid((unsigned)((npix + 127) / 128));   // 8 segments of 16 pixels per workgroup
       if (esz == 4)
         hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, s, input, wf32 + o.wgt_off,
                            wf32 + o.bias_off, (float *)buf(o.out_off), B, H, W, o.Ho, o.Wo, o.out_ld);
