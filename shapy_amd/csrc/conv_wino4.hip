@@ -58,6 +58,24 @@ namespace shapy {
 // or 4 (N = 64, 320 threads: layers whose Cout is a multiple of 64 but not of 48 -- layer1's 64 -> 64
 // and the head's 512 -> 512; five waves of 256 registers leave room for ONE workgroup per CU, all four
 // SIMDs multiply and the staging wave shares one of them).
+#ifdef SHAPY_W4_TOKEN
+// A/B variant (never built into the product library; first GPU run of round 5, tools/runs/r05_a.sh).
+// tools/prio_probe.hip showed that s_setprio does NOT arbitrate the matrix pipe between the two waves of a
+// SIMD (2,265 vs 2,297 us for the higher / lower priority, profiles/r04ab_prio_probe.txt), so the two
+// workgroups of a CU always share it, finish their multiply phases together and run their epilogues
+// together with the pipe idle.  Here the multiply phase of a short (<= SHAPY_W4_TOKEN
+// chunks) workgroup is bracketed by a per-CU token in global memory (both residents sit behind the same
+// XCD's L2, where the atomics execute): one workgroup multiplies at the full rate while the other runs its
+// epilogue / next prologue.  Timing only -- no data depends on the token -- hence relaxed atomics.
+__device__ int w4_token[16 * 256];
+__device__ __forceinline__ int *w4_token_slot() {
+  unsigned hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  return w4_token + (xcc & 15u) * 256 + ((hw >> 8) & 255u);           // XCC | SE, SH, CU
+}
+#endif
+
 template <int KC, int NW = 3>
 __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
   constexpr int N = 16 * NW;
@@ -180,6 +198,22 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
 #ifdef SHAPY_W4_PRIO
   __builtin_amdgcn_s_setprio(SHAPY_W4_PRIO);    // A/B: multiplying waves above the staging waves
 #endif
+#ifdef SHAPY_W4_PRIO_PARITY
+  // A/B: the two workgroups of a CU get DIFFERENT issue priorities for their multiply phases (wave slot
+  // id of the SIMD, low two bits), so that the matrix pipe serves one of them at full rate and that one
+  // reaches its epilogue while the other still multiplies, instead of both sharing the pipe and then
+  // both finishing at once (in-phase residents).  Back to 0 for the epilogue.
+  {
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    switch (hw_id & 3u) {
+      case 0: __builtin_amdgcn_s_setprio(3); break;
+      case 1: __builtin_amdgcn_s_setprio(2); break;
+      case 2: __builtin_amdgcn_s_setprio(1); break;
+      default: __builtin_amdgcn_s_setprio(0); break;
+    }
+  }
+#endif
   const __amdgpu_buffer_rsrc_t rs_u =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt2), 0, p.wgt2_bytes, 0x00020000);
   const int g = lane >> 4, l15 = lane & 15;
@@ -202,6 +236,18 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
   for (int q = 0; q < 36; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < R; ++q) bload(q, q, 0, true);
+#ifdef SHAPY_W4_TOKEN
+  // (after the ring preload is in flight, before the first chunk barrier: the other waves of the
+  // workgroup wait at that barrier for this one)
+  int *tok = nullptr;
+  if (KC > 0 && KC <= SHAPY_W4_TOKEN && NW == 3 && wave == 0) {
+    tok = w4_token_slot();
+    if (lane == 0)
+      while (__hip_atomic_exchange(tok, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        __builtin_amdgcn_s_sleep(8);
+    asm volatile("" ::: "memory");
+  }
+#endif
 
   auto chunk = [&](int cc, bool more) {
     wino4_lds_barrier();                     // chunk cc is staged
@@ -267,7 +313,13 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
     for (int cc = 0; cc < CC; ++cc) chunk(cc, cc + 1 < CC);
   }
   wino4_lds_barrier();                       // barrier #CC: the staging wave's closing one
+#ifdef SHAPY_W4_TOKEN
+  if (tok && lane == 0) __hip_atomic_store(tok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 
+#ifdef SHAPY_W4_PRIO_PARITY
+  __builtin_amdgcn_s_setprio(0);
+#endif
   // ---- epilogue: output transform in registers, bias + residual + ReLU, 16-byte stores ----
   // (conv_wino4.h; per lane: tile m_blk + l15, channels n0 + 4 g .. + 3)
   Wino4Epi e;
