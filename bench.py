@@ -95,7 +95,7 @@ def launches_per_forward(plan):
 def conv_flop_per_image(net, size, plan=None):
     plan = plan or _f32_plan(net, size)              # f32 plan: algorithmic (unpadded) MACs
     macs = sum(o['Ho'] * o['Wo'] * o['Cout'] * o['Cin'] * o['ksize'] ** 2
-               for o in plan.ops if o['type'] != 2)
+               for o in plan.ops if o['type'] in (0, 1))          # CONV, STEM (not MEANPOOL / FUSEADD)
     return 2 * macs
 
 
@@ -107,7 +107,7 @@ def executed_mfma_flop_per_image(net, size, plan=None):
     plan = plan or _f32_plan(net, size)
     macs = 0
     for o in plan.ops:
-        if o['type'] == 2:
+        if o['type'] not in (0, 1):
             continue
         cc = o['Cout'] * o['Cin']
         if o.get('wino_off', -1) >= 0 and o['tile'] & _lib.TILE_WINO4:
@@ -651,6 +651,8 @@ def run_regressor(args, rank, world, local_rank):
             net.backbone.tile_flags = int(args.tile_flags, 0)
         if getattr(args, 'group_branches', None):
             net.backbone.group_branches = {'auto': 'auto', 'on': True, 'off': False}[args.group_branches]
+        if getattr(args, 'fuse_add', None):
+            net.backbone.fuse_add = args.fuse_add == 'on'
     B = args.batch
     # distinct synthetic images per rank (global batch = world * B), resident in HBM
     x_np = syn.synthetic_images(B, args.size, 100 + rank)
@@ -809,6 +811,7 @@ def run_regressor(args, rank, world, local_rank):
                    'global_batch': world * B, 'parallelism': f'dp{world}',
                    'multi_stream': not args.single_stream, 'conv_algo': algo,
                    'd2h_betas_in_timed_region': True,
+                   'fuse_add': bool(net.backbone.fuse_add),
                    'hip_graph': ('explicit' if net.backbone.use_graph == 'explicit' else
                                  bool(net.backbone.use_graph is True or
                                       (net.backbone.use_graph == 'auto' and
@@ -905,6 +908,9 @@ def main():
     ap.add_argument('--group-branches', default=None, choices=['auto', 'on', 'off'],
                     help='persistent grouped F(4x4) launches per depth level of a module '
                          '(HighResolutionNet.group_branches)')
+    ap.add_argument('--fuse-add', default=None, choices=['on', 'off'],
+                    help='upsample terms of the fuse layers as low-resolution convs + one add pass '
+                         '(HighResolutionNet.fuse_add; default: the backbone\'s own, off)')
     ap.add_argument('--no-also', action='store_true',
                     help='skip the `also` sub-records (the other BASELINE configurations, timed after '
                          'the headline\'s timed region in the default N = 1 run)')

@@ -53,7 +53,7 @@ class ShapySmplxModel(ctypes.Structure):
                 ('dyn_lmk_bary', vp), ('neck_kin_chain', vp)]
 
 
-OP_CONV, OP_STEM, OP_MEANPOOL = 0, 1, 2
+OP_CONV, OP_STEM, OP_MEANPOOL, OP_FUSEADD = 0, 1, 2, 3
 POSE_ROTMAT, POSE_CONT6D, POSE_AXIS_ANGLE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F32X6 = 0, 1, 2
 TILES = {'auto': 0, '256x48': 1, '128x96': 2, '128x128': 3, '256x64': 4, '64x48': 5,

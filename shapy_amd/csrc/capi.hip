@@ -7,7 +7,7 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
               int dtype, hipStream_t main);
 }
 
-extern "C" int shapy_abi_version(void) { return 6; }
+extern "C" int shapy_abi_version(void) { return 7; }
 extern "C" const char *shapy_build_arch(void) { return "gfx950"; }
 
 extern "C" int shapy_conv2d(const ShapyConv *d, void *stream) {

@@ -159,6 +159,80 @@ __global__ void mean_pool_kernel(const InT *__restrict__ in, float *__restrict__
   out[i] = s / (float)HW;
 }
 
+// ---- upsample terms of a fuse output in ONE pass (hrnet.py:181-191) ----
+// out = [relu](base + up2(y1) [+ up4(y2) [+ up8(y3)]]), nearest upsampling, terms added in this order.
+// base / out: [B, H, W] rows of `ld` elements (they may be the same tensor: a thread reads and writes
+// only its own 16 bytes); y_t: dense [B, H >> (t+1), W >> (t+1), C].  A thread owns 16 bytes of a pixel
+// (4 floats / 8 bf16): every access is a full-width vector access, consecutive lanes are contiguous.
+// Replaces the upsample-scatter epilogue of the conv kernel for these layers (fuse_add plans): that
+// epilogue moves 4 bytes per lane and instruction to UPS x UPS scattered pixels and re-reads and
+// re-writes the whole output once per term -- 38 + 67 + 86 us for the three terms of the 56 x 56
+// output of a stage-4 module at B = 64 (profiles/r04o_timeline_*), a 20 us job by traffic.
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float *p, float (&v)[4]) {
+    const f32x4 x = *reinterpret_cast<const f32x4 *>(p);
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+  }
+  static __device__ __forceinline__ void store(float *p, const float (&v)[4]) {
+    *reinterpret_cast<f32x4 *>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+};
+template <>
+struct Vec16<unsigned short> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const unsigned short *p, float (&v)[8]) {
+    const u32x4 x = *reinterpret_cast<const u32x4 *>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = __uint_as_float(x[e] << 16);
+      v[2 * e + 1] = __uint_as_float(x[e] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store(unsigned short *p, const float (&v)[8]) {
+    store_row8(p, v);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_add_kernel(const T *__restrict__ base, T *out,
+                                                       const T *__restrict__ y1,
+                                                       const T *__restrict__ y2,
+                                                       const T *__restrict__ y3, long n_vec, int H,
+                                                       int W, int C, int base_ld, int base_coff,
+                                                       int out_ld, int out_coff, int relu) {
+  constexpr int N = Vec16<T>::N;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_vec) return;
+  const int cv = C / N;                       // 16-byte vectors per pixel
+  const int c = (int)(i % cv) * N;
+  const long pix = i / cv;
+  const int x = (int)(pix % W);
+  const long q = pix / W;
+  const int y = (int)(q % H);
+  const long b = q / H;
+  float acc[N], t[N];
+  Vec16<T>::load(base + pix * base_ld + base_coff + c, acc);
+  const T *ys[3] = {y1, y2, y3};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (!ys[k]) break;
+    const int sh = k + 1;
+    const int Hk = H >> sh, Wk = W >> sh;
+    Vec16<T>::load(ys[k] + ((b * Hk + (y >> sh)) * Wk + (x >> sh)) * (long)C + c, t);
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] += t[e];
+  }
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = fmaxf(acc[e], 0.f);
+  }
+  Vec16<T>::store(out + pix * out_ld + out_coff + c, acc);
+}
+
 // ---- side streams for the independent branches of a HighResolutionModule ----
 constexpr int N_SIDE = 6;        // side streams: lanes 1..3 = branches, 4..6 = auxiliary chains
 constexpr int N_EVENTS = 64;     // dependency events (ShapyOp.sig / .wait), reused from epoch to epoch
@@ -358,6 +432,31 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
         hipLaunchKernelGGL(mean_pool_kernel<unsigned short>, grid, dim3(256), 0, s,
                            (const unsigned short *)buf(o.in_off), features_out, o.Hi * o.Wi, o.Cin,
                            o.in_ld, total);
+      SHAPY_HIP_TRY(hipGetLastError());
+    } else if (o.type == SHAPY_OP_FUSEADD) {
+      // Ho x Wo x Cout output; res = the base tensor; in_off / wgt_off / bias_off = the up to three
+      // low-resolution terms in the WORKSPACE (upsample factors 2, 4, 8; ksize = how many)
+      const int nv = esz == 4 ? 4 : 8;
+      if (o.ksize < 1 || o.ksize > 3 || o.res_off < 0 || o.out_off < 0 || o.in_off < 0 ||
+          (o.ksize > 1 && o.wgt_off < 0) || (o.ksize > 2 && o.bias_off < 0) || o.Cout % nv ||
+          o.out_ld % nv || o.out_coff % nv || o.res_ld % nv || o.res_coff % nv ||
+          (o.Ho & ((1 << o.ksize) - 1)) || (o.Wo & ((1 << o.ksize) - 1)))
+        return SHAPY_EINVAL;
+      const long n_vec = (long)B * o.Ho * o.Wo * (o.Cout / nv);
+      const dim3 grid((unsigned)((n_vec + 255) / 256));
+      char *y1 = buf(o.in_off), *y2 = o.ksize > 1 ? buf(o.wgt_off) : nullptr,
+           *y3 = o.ksize > 2 ? buf(o.bias_off) : nullptr;
+      if (esz == 4)
+        hipLaunchKernelGGL(fuse_add_kernel<float>, grid, dim3(256), 0, s, (const float *)buf(o.res_off),
+                           (float *)buf(o.out_off), (const float *)y1, (const float *)y2,
+                           (const float *)y3, n_vec, o.Ho, o.Wo, o.Cout, o.res_ld, o.res_coff, o.out_ld,
+                           o.out_coff, o.relu);
+      else
+        hipLaunchKernelGGL(fuse_add_kernel<unsigned short>, grid, dim3(256), 0, s,
+                           (const unsigned short *)buf(o.res_off), (unsigned short *)buf(o.out_off),
+                           (const unsigned short *)y1, (const unsigned short *)y2,
+                           (const unsigned short *)y3, n_vec, o.Ho, o.Wo, o.Cout, o.res_ld, o.res_coff,
+                           o.out_ld, o.out_coff, o.relu);
       SHAPY_HIP_TRY(hipGetLastError());
     } else {
       return SHAPY_EINVAL;

@@ -36,6 +36,7 @@ BN_MOMENTUM = 0.1
 DEFAULT_CONV_ALGO = 'winograd4'
 DEFAULT_WINO4_MIN_HW = 7
 DEFAULT_WINO4_N64 = '0'
+DEFAULT_FUSE_ADD = '0'
 
 
 # ------------------------------------------------------------------------------------------
@@ -251,7 +252,7 @@ class _Plan:
             t = len(self.ops)
             if kw['group'] > 1:
                 self._group_left, self._group_t = kw['group'] - 1, t
-        for key in ('inb', 'outb', 'resb'):
+        for key in ('inb', 'outb', 'resb', 'inb2', 'inb3'):
             b = kw.get(key)
             if b is not None:
                 b.uses.append((self.epoch, kw['lane'], t))
@@ -259,8 +260,9 @@ class _Plan:
         # residual: the output's slice), write-after-read / -write on the slice written
         i, deps = len(self.ops), set()
         acc = []
-        if kw.get('inb') is not None:
-            acc.append((kw['inb'], False, 0, kw['inb'].C))
+        for key in ('inb', 'inb2', 'inb3'):          # (inb2 / inb3: the further terms of a FUSEADD op)
+            if kw.get(key) is not None:
+                acc.append((kw[key], False, 0, kw[key].C))
         if kw.get('resb') is not None:
             acc.append((kw['resb'], False, kw['res_coff'], kw['res_coff'] + kw['Cout']))
         if kw.get('outb') is not None:
@@ -494,6 +496,14 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: profiles/r04t_*), and on the head's 512 -> 512 @7x7 it loses (131 vs 100 us)
         self.wino4_n64 = os.environ.get('SHAPY_WINO4_N64', DEFAULT_WINO4_N64) == '1'
         self.wino4_n64_min_hw = int(os.environ.get('SHAPY_WINO4_N64_MIN_HW', '28'))
+        #: the upsample terms of a fuse output (reference hrnet.py:181-191: 1x1 conv + BN + nearest
+        #: Upsample, added to the output) as plain low-resolution convs + ONE add pass over the output
+        #: (SHAPY_OP_FUSEADD) instead of one upsample-scatter conv per term.  Written at the end of
+        #: round 4 from the timeline (191 us of scatter epilogues per stage-4 module on the critical
+        #: lane, a 20 us job by traffic) after the GPU budget was spent: OFF until it has run on
+        #: hardware (tests/test_zz_fuse_add_gpu.py is its first run; the plan and its arithmetic are
+        #: checked on the CPU by tests/test_plan_replay.py)
+        self.fuse_add = os.environ.get('SHAPY_FUSE_ADD', DEFAULT_FUSE_ADD) == '1'
 
         #: conv_algo='winograd4': the convs at the same depth of a HighResolutionModule's parallel
         #: branches as ONE persistent grouped launch (csrc/conv_wino4g.hip) instead of one launch
@@ -843,6 +853,20 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                             t, Ht, Wt = conv(fl[k][0], fl[k][1], t, Ht, Wt, relu=True,
                                              lane=chain_lane, name=f'{name}.fuse_layers.{i}.{j}.{k}')
                         lead[(i, j)] = (t, Ht, Wt)
+            # fuse_add: the upsample terms (j > i) of an output are computed ONCE at their own
+            # resolution -- plain 1x1 convs on the lane of their source branch, enqueued here so that
+            # they run as soon as that branch is done -- and added in one pass over the output
+            # (OP_FUSEADD) instead of one upsample-scatter conv per term, each of which re-reads and
+            # re-writes the whole output with 4-byte accesses
+            fadd = bool(self.fuse_add) and not grouped
+            low = {}                        # (i, j) -> low-resolution term y_ij
+            if fadd:
+                for i in range(len(m.fuse_layers)):
+                    for j in range(i + 1, nb):
+                        xj, Hj, Wj = ys[j]
+                        fl = m.fuse_layers[i][j]
+                        low[(i, j)], _, _ = conv(fl[0], fl[1], xj, Hj, Wj, lane=j if dag else i,
+                                                 name=f'{name}.fuse_layers.{i}.{j}')
             outs = []
             for i in range(len(m.fuse_layers)):
                 xi, Hi_, Wi_ = ys[i]
@@ -851,8 +875,14 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 outb = last_out[0] if use_last else P.buf(Hi_, Wi_, xi.C)
                 o_ld = last_out[1] if use_last else xi.C
                 o_co = last_out[2] if use_last else 0
+                if fadd and i < nb - 1:
+                    # the stride-2 chains (j < i) accumulate as before, WITHOUT the final ReLU; then
+                    # out = relu(base + up(y_i,i+1) + up(y_i,i+2) + ...), base = x_i if i == 0
+                    terms = [j for j in terms if j < i]
                 for ti, j in enumerate(terms):
                     first, last = ti == 0, ti == len(terms) - 1
+                    if fadd and i < nb - 1:
+                        last = False
                     res = xi if first else outb
                     r_ld = xi.C if first else o_ld
                     r_co = 0 if first else o_co
@@ -874,6 +904,17 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                             else:
                                 t, Ht, Wt = conv(fl[k][0], fl[k][1], t, Ht, Wt, relu=True, lane=i,
                                                  name=f'{nm}.{k}')
+                if fadd and i < nb - 1:
+                    ups_terms = [low[(i, j)] for j in range(i + 1, nb)]
+                    assert 1 <= len(ups_terms) <= 3 and not use_last
+                    base = xi if not terms else outb
+                    P.op(type=_lib.OP_FUSEADD, lane=i, inb=ups_terms[0],
+                         inb2=ups_terms[1] if len(ups_terms) > 1 else None,
+                         inb3=ups_terms[2] if len(ups_terms) > 2 else None,
+                         outb=outb, resb=base, Hi=Hi_, Wi=Wi_, Cin=xi.C, in_ld=xi.C, Ho=Hi_, Wo=Wi_,
+                         Cout=xi.C, ksize=len(ups_terms), stride=1, pad=0, out_ld=o_ld, out_coff=o_co,
+                         res_ld=base.C, res_coff=0, relu=1, ups=2, tile=0, wgt_off=-1, bias_off=-1,
+                         wino_off=-1, name=f'{name}.fuse_add.{i}')
                 outs.append((outb, Hi_, Wi_))
             return outs
 
@@ -950,7 +991,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             self._engine_ver = ver
         key = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
                self.wino4_min_hw, self._group_on(), self._dag_eff, self.dag_aux, self.dag_no_barriers, self.dag_balance,
-               self.wino4_n64, self.wino4_n64_min_hw,
+               self.wino4_n64, self.wino4_n64_min_hw, bool(self.fuse_add),
                tuple(sorted(self.layer_algo.items())),
                self.tile_flags, tuple(sorted(self.tile_overrides.items())))
         eng = self._engine.get(key)
@@ -972,6 +1013,9 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             a.in_off = -2 if o['type'] == _lib.OP_STEM else o['inb'].off
             a.out_off = -1 if o['outb'] is None else o['outb'].off
             a.res_off = -1 if o['resb'] is None else o['resb'].off
+            if o['type'] == _lib.OP_FUSEADD:      # terms 2 / 3 travel in the weight-offset fields
+                a.wgt_off = -1 if o.get('inb2') is None else o['inb2'].off
+                a.bias_off = -1 if o.get('inb3') is None else o['inb3'].off
         blob = np.frombuffer(b''.join(P.wchunks), dtype=np.uint8)
         weights = torch.from_numpy(blob.copy()).to(device)
         eng = dict(ops=arr, n_ops=n, weights=weights, ws_per_img=ws_per_img, plan=P, ws=None,

@@ -55,7 +55,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.shapy_abi_version() == 6
+    assert lib.shapy_abi_version() == 7
     assert lib.shapy_build_arch() == b'gfx950'
     # struct layouts agree with the C header (sizeof through a tiny C program)
     src = '#include <stdio.h>\n#include "shapy_hip.h"\nint main(){printf("%zu %zu %zu", ' \
@@ -140,7 +140,8 @@ def _executor_order(ops):
 
 
 @pytest.mark.parametrize('dag,group,aux', [(True, False, False), (True, False, True), (True, False, 'nobar'),
-                                           (False, False, False), (False, True, False)])
+                                           (False, False, False), (False, True, False),
+                                           (True, False, 'fuse_add'), (False, False, 'fuse_add')])
 def test_plan_orders_every_memory_hazard(hrnet, dag, group, aux):
     """The executor's order (lanes, barriers, dependency events, launch groups) covers every hazard
     of the PACKED workspace: whenever two ops touch overlapping memory and at least one of them
@@ -150,12 +151,15 @@ def test_plan_orders_every_memory_hazard(hrnet, dag, group, aux):
     try:
         hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw = dag, group, 'winograd4', 7
         hrnet.dag_aux, hrnet.dag_no_barriers = aux is True, aux == 'nobar'
+        hrnet.fuse_add = aux == 'fuse_add'
         P = hrnet._build_plan(224, 224)
         waits = P.sync_plan()
         total = P.allocate()
     finally:
-        hrnet.dag_aux = hrnet.dag_no_barriers = False
+        hrnet.dag_aux = hrnet.dag_no_barriers = hrnet.fuse_add = False
         hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw = keep
+    if aux == 'fuse_add':
+        assert sum(1 for o in P.ops if o['type'] == 3) == 18 and not any(o['ups'] > 1 for o in P.ops if o['type'] == 0)
     ops = P.ops
     reach = _executor_order(ops)
     if dag:
@@ -165,7 +169,8 @@ def test_plan_orders_every_memory_hazard(hrnet, dag, group, aux):
     # memory accesses: (op, write?, first float, end float, channel window inside a pixel row)
     acc = []
     for i, o in enumerate(ops):
-        for key, is_w, c0, cn in (('inb', False, 0, None), ('resb', False, o['res_coff'], o['Cout']),
+        for key, is_w, c0, cn in (('inb', False, 0, None), ('inb2', False, 0, None), ('inb3', False, 0, None),
+                                  ('resb', False, o['res_coff'], o['Cout']),
                                   ('outb', True, o['out_coff'], o['Cout'])):
             b = o.get(key)
             if b is None:
@@ -191,25 +196,26 @@ def test_plan_orders_every_memory_hazard(hrnet, dag, group, aux):
     assert total * 4 / 1e6 < 20.0            # MB per 224x224 image: packing works (no reuse: 112 MB)
 
 
-@pytest.mark.parametrize('size', [64, 256])
-def test_event_driven_plan_at_other_input_sizes(hrnet, size):
+@pytest.mark.parametrize('size,fuse_add', [(64, False), (256, False), (64, True), (256, True)])
+def test_event_driven_plan_at_other_input_sizes(hrnet, size, fuse_add):
     """The dependency events fit their 64 slots and at most three waits per op at the sizes the
     reference uses besides 224 (256: expose configs; 64: the smallest legal input), and the
     executor's order still covers every hazard of the packed workspace."""
     keep = hrnet._dag_eff, hrnet.conv_algo
     try:
-        hrnet._dag_eff, hrnet.conv_algo = True, 'winograd4'
+        hrnet._dag_eff, hrnet.conv_algo, hrnet.fuse_add = True, 'winograd4', fuse_add
         P = hrnet._build_plan(size, size)
         waits = P.sync_plan()
         total = P.allocate()
     finally:
         hrnet._dag_eff, hrnet.conv_algo = keep
+        hrnet.fuse_add = False
     ops = P.ops
     assert max(len(w) for w in waits) <= 3 and max(o['sig'] for o in ops) < 64
     reach = _executor_order(ops)
     spans = []
     for i, o in enumerate(ops):
-        for key, is_w in (('inb', False), ('resb', False), ('outb', True)):
+        for key, is_w in (('inb', False), ('inb2', False), ('inb3', False), ('resb', False), ('outb', True)):
             b = o.get(key)
             if b is not None:
                 spans.append((i, is_w, b.off, b.off + b.size, id(b)))

@@ -17,3 +17,9 @@ for rep in 1 2 3; do for v in "" variants/libtok3.so variants/libtok6.so; do
   if [ -n "$v" ]; then export SHAPY_HIP_LIB=$PWD/shapy_amd/csrc/$v; else unset SHAPY_HIP_LIB; fi
   echo "rep $rep ${v:-product}: $(timeout 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-also 2>/dev/null | grep '^{' | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "img/s", round(d["roofline"]["ms_per_launch_group"],3), "ms backbone")')"
 done; done 2>&1 | tee $O/token_bench.txt
+# --- second prepared experiment: the fuse_add plans (HighResolutionNet.fuse_add) ---
+unset SHAPY_HIP_LIB
+timeout 600 python -m pytest tests/test_zz_fuse_add_gpu.py -q -rA 2>&1 | tail -15 | tee $O/fuse_add_tests.txt
+for rep in 1 2 3; do for fa in off on; do
+  echo "rep $rep fuse_add $fa: $(timeout 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-also --fuse-add $fa 2>/dev/null | grep '^{' | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "img/s", round(d["roofline"]["ms_per_launch_group"],3), "ms backbone")')"
+done; done 2>&1 | tee $O/fuse_add_bench.txt
