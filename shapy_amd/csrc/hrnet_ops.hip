@@ -198,7 +198,7 @@ struct Vec16<unsigned short> {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void fuse_add_kernel(const T *__restrict__ base, T *out,
+__global__ __launch_bounds__(256) void fuse_add_kernel(const T *base, T *out,   // (may be one tensor)
                                                        const T *__restrict__ y1,
                                                        const T *__restrict__ y2,
                                                        const T *__restrict__ y3, long n_vec, int H,
