@@ -164,10 +164,11 @@ __global__ void mean_pool_kernel(const InT *__restrict__ in, float *__restrict__
 // base / out: [B, H, W] rows of `ld` elements (they may be the same tensor: a thread reads and writes
 // only its own 16 bytes); y_t: dense [B, H >> (t+1), W >> (t+1), C].  A thread owns 16 bytes of a pixel
 // (4 floats / 8 bf16): every access is a full-width vector access, consecutive lanes are contiguous.
-// Replaces the upsample-scatter epilogue of the conv kernel for these layers (fuse_add plans): that
-// epilogue moves 4 bytes per lane and instruction to UPS x UPS scattered pixels and re-reads and
-// re-writes the whole output once per term -- 38 + 67 + 86 us for the three terms of the 56 x 56
-// output of a stage-4 module at B = 64 (profiles/r04o_timeline_*), a 20 us job by traffic.
+// Replaces the upsample-scatter epilogue of the conv kernel for these layers (fuse_add plans): there the
+// FEW workgroups of the low-resolution GEMM (49 for the 7 x 7 source of a stage-4 module at B = 64, 196
+// for 14 x 14) each re-read and re-write UPS x UPS times their tile of the output, and the whole output
+// travels once per term -- 38 + 67 + 86 us for the three terms of the 56 x 56 output of a stage-4
+// module at B = 64 (profiles/r04o_timeline_*), a 20 us job by traffic.
 template <typename T>
 struct Vec16;
 template <>

@@ -857,7 +857,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             # resolution -- plain 1x1 convs on the lane of their source branch, enqueued here so that
             # they run as soon as that branch is done -- and added in one pass over the output
             # (OP_FUSEADD) instead of one upsample-scatter conv per term, each of which re-reads and
-            # re-writes the whole output with 4-byte accesses
+            # re-writes the whole output from the few workgroups of a low-resolution GEMM
             fadd = bool(self.fuse_add) and not grouped
             low = {}                        # (i, j) -> low-resolution term y_ij
             if fadd:
