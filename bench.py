@@ -652,7 +652,9 @@ def run_regressor(args, rank, world, local_rank):
         if getattr(args, 'group_branches', None):
             net.backbone.group_branches = {'auto': 'auto', 'on': True, 'off': False}[args.group_branches]
         if getattr(args, 'fuse_add', None):
-            net.backbone.fuse_add = args.fuse_add == 'on'
+            net.backbone.fuse_add = {'off': 0, 'on': 1, '0': 0, '1': 1, '2': 2}[args.fuse_add]
+        if getattr(args, 'fuse_chain_lanes', None):
+            net.backbone.fuse_chain_lanes = args.fuse_chain_lanes
     B = args.batch
     # distinct synthetic images per rank (global batch = world * B), resident in HBM
     x_np = syn.synthetic_images(B, args.size, 100 + rank)
@@ -811,7 +813,7 @@ def run_regressor(args, rank, world, local_rank):
                    'global_batch': world * B, 'parallelism': f'dp{world}',
                    'multi_stream': not args.single_stream, 'conv_algo': algo,
                    'd2h_betas_in_timed_region': True,
-                   'fuse_add': bool(net.backbone.fuse_add),
+                   'fuse_add': int(net.backbone.fuse_add),
                    'hip_graph': ('explicit' if net.backbone.use_graph == 'explicit' else
                                  bool(net.backbone.use_graph is True or
                                       (net.backbone.use_graph == 'auto' and
@@ -908,9 +910,13 @@ def main():
     ap.add_argument('--group-branches', default=None, choices=['auto', 'on', 'off'],
                     help='persistent grouped F(4x4) launches per depth level of a module '
                          '(HighResolutionNet.group_branches)')
-    ap.add_argument('--fuse-add', default=None, choices=['on', 'off'],
-                    help='upsample terms of the fuse layers as low-resolution convs + one add pass '
-                         '(HighResolutionNet.fuse_add; default: the backbone\'s own, off)')
+    ap.add_argument('--fuse-add', default=None, choices=['on', 'off', '0', '1', '2'],
+                    help='upsample terms of the fuse layers as low-resolution convs + one add pass (1 = on); '
+                         '2: also the stride-2 terms accumulated apart from x_i, one short add per output '
+                         '(HighResolutionNet.fuse_add; default: the backbone\'s own, 0)')
+    ap.add_argument('--fuse-chain-lanes', default=None,
+                    help='with --fuse-add 2: lane policy of the stride-2 chains per stage, e.g. '
+                         '"dest,dest,mixed" (HighResolutionNet.fuse_chain_lanes)')
     ap.add_argument('--no-also', action='store_true',
                     help='skip the `also` sub-records (the other BASELINE configurations, timed after '
                          'the headline\'s timed region in the default N = 1 run)')

@@ -142,12 +142,13 @@ int shapy_conv2d_group(const ShapyConv *descs_host, int n, void *stream);
  * offsets (in floats, per image) into one workspace allocation that is scaled by B.
  * ------------------------------------------------------------------------------------- */
 enum { SHAPY_OP_CONV = 0, SHAPY_OP_STEM = 1, SHAPY_OP_MEANPOOL = 2, SHAPY_OP_FUSEADD = 3 };
-/* SHAPY_OP_FUSEADD (ABI 7): out[Ho, Wo, Cout] = [relu](res + up2(y1) [+ up4(y2) [+ up8(y3)]]) -- the
-   nearest-upsampled terms of one fuse output of a HighResolutionModule (reference hrnet.py:181-191) added
-   in ONE pass over the output, in this order.  res_off / res_ld / res_coff: the base tensor (may be the
-   output itself); ksize = number of terms (1..3); in_off, wgt_off, bias_off = per-image WORKSPACE offsets
-   of y1, y2, y3 (dense [Ho >> t, Wo >> t, Cout], t = 1, 2, 3), each produced by an ordinary 1x1 CONV op
-   at its own resolution.  Cout, the leading dimensions and channel offsets must be multiples of 16 bytes. */
+/* SHAPY_OP_FUSEADD (ABI 7): out[Ho, Wo, Cout] = [relu](res [+ extra] [+ up2(y1) [+ up4(y2) [+ up8(y3)]]])
+   -- the terms of one fuse output of a HighResolutionModule (reference hrnet.py:181-191) added in ONE pass
+   over the output, in this order.  res_off / res_ld / res_coff: the base tensor (may be the output itself);
+   wino_off: per-image WORKSPACE offset of a second full-resolution term (dense [Ho, Wo, Cout]; -1: none);
+   ksize = number of nearest-upsampled terms (0..3); in_off, wgt_off, bias_off = WORKSPACE offsets of y1,
+   y2, y3 (dense [Ho >> t, Wo >> t, Cout], t = 1, 2, 3), each produced by an ordinary 1x1 CONV op at its
+   own resolution.  Cout, the leading dimensions and channel offsets must be multiples of 16 bytes. */
 
 typedef struct ShapyOp {
   int32_t type;

@@ -160,9 +160,10 @@ __global__ void mean_pool_kernel(const InT *__restrict__ in, float *__restrict__
 }
 
 // ---- upsample terms of a fuse output in ONE pass (hrnet.py:181-191) ----
-// out = [relu](base + up2(y1) [+ up4(y2) [+ up8(y3)]]), nearest upsampling, terms added in this order.
-// base / out: [B, H, W] rows of `ld` elements (they may be the same tensor: a thread reads and writes
-// only its own 16 bytes); y_t: dense [B, H >> (t+1), W >> (t+1), C].  A thread owns 16 bytes of a pixel
+// out = [relu](base [+ extra] [+ up2(y1) [+ up4(y2) [+ up8(y3)]]]), nearest upsampling, terms added in
+// this order.  base / out: [B, H, W] rows of `ld` elements (they may be the same tensor: a thread reads
+// and writes only its own 16 bytes); extra: dense [B, H, W, C] (the separately accumulated stride-2
+// terms of the output, fuse_add = 2 plans); y_t: dense [B, H >> (t+1), W >> (t+1), C].  A thread owns 16 bytes of a pixel
 // (4 floats / 8 bf16): every access is a full-width vector access, consecutive lanes are contiguous.
 // Replaces the upsample-scatter epilogue of the conv kernel for these layers (fuse_add plans): there the
 // FEW workgroups of the low-resolution GEMM (49 for the 7 x 7 source of a stage-4 module at B = 64, 196
@@ -200,6 +201,7 @@ struct Vec16<unsigned short> {
 
 template <typename T>
 __global__ __launch_bounds__(256) void fuse_add_kernel(const T *base, T *out,   // (may be one tensor)
+                                                       const T *__restrict__ extra,
                                                        const T *__restrict__ y1,
                                                        const T *__restrict__ y2,
                                                        const T *__restrict__ y3, long n_vec, int H,
@@ -217,6 +219,11 @@ __global__ __launch_bounds__(256) void fuse_add_kernel(const T *base, T *out,   
   const long b = q / H;
   float acc[N], t[N];
   Vec16<T>::load(base + pix * base_ld + base_coff + c, acc);
+  if (extra) {
+    Vec16<T>::load(extra + pix * (long)C + c, t);
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] += t[e];
+  }
   const T *ys[3] = {y1, y2, y3};
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -435,27 +442,28 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
                            o.in_ld, total);
       SHAPY_HIP_TRY(hipGetLastError());
     } else if (o.type == SHAPY_OP_FUSEADD) {
-      // Ho x Wo x Cout output; res = the base tensor; in_off / wgt_off / bias_off = the up to three
-      // low-resolution terms in the WORKSPACE (upsample factors 2, 4, 8; ksize = how many)
+      // Ho x Wo x Cout output; res = the base tensor; wino_off = a second full-resolution term (-1:
+      // none); in_off / wgt_off / bias_off = the up to three low-resolution terms -- all offsets into
+      // the WORKSPACE (upsample factors 2, 4, 8; ksize = how many, 0..3)
       const int nv = esz == 4 ? 4 : 8;
-      if (o.ksize < 1 || o.ksize > 3 || o.res_off < 0 || o.out_off < 0 || o.in_off < 0 ||
+      if (o.ksize < 0 || o.ksize > 3 || o.res_off < 0 || o.out_off < 0 || (o.ksize > 0 && o.in_off < 0) ||
           (o.ksize > 1 && o.wgt_off < 0) || (o.ksize > 2 && o.bias_off < 0) || o.Cout % nv ||
           o.out_ld % nv || o.out_coff % nv || o.res_ld % nv || o.res_coff % nv ||
           (o.Ho & ((1 << o.ksize) - 1)) || (o.Wo & ((1 << o.ksize) - 1)))
         return SHAPY_EINVAL;
       const long n_vec = (long)B * o.Ho * o.Wo * (o.Cout / nv);
       const dim3 grid((unsigned)((n_vec + 255) / 256));
-      char *y1 = buf(o.in_off), *y2 = o.ksize > 1 ? buf(o.wgt_off) : nullptr,
-           *y3 = o.ksize > 2 ? buf(o.bias_off) : nullptr;
+      char *y1 = o.ksize > 0 ? buf(o.in_off) : nullptr, *y2 = o.ksize > 1 ? buf(o.wgt_off) : nullptr,
+           *y3 = o.ksize > 2 ? buf(o.bias_off) : nullptr, *ex = buf(o.wino_off);
       if (esz == 4)
         hipLaunchKernelGGL(fuse_add_kernel<float>, grid, dim3(256), 0, s, (const float *)buf(o.res_off),
-                           (float *)buf(o.out_off), (const float *)y1, (const float *)y2,
+                           (float *)buf(o.out_off), (const float *)ex, (const float *)y1, (const float *)y2,
                            (const float *)y3, n_vec, o.Ho, o.Wo, o.Cout, o.res_ld, o.res_coff, o.out_ld,
                            o.out_coff, o.relu);
       else
         hipLaunchKernelGGL(fuse_add_kernel<unsigned short>, grid, dim3(256), 0, s,
                            (const unsigned short *)buf(o.res_off), (unsigned short *)buf(o.out_off),
-                           (const unsigned short *)y1, (const unsigned short *)y2,
+                           (const unsigned short *)ex, (const unsigned short *)y1, (const unsigned short *)y2,
                            (const unsigned short *)y3, n_vec, o.Ho, o.Wo, o.Cout, o.res_ld, o.res_coff,
                            o.out_ld, o.out_coff, o.relu);
       SHAPY_HIP_TRY(hipGetLastError());

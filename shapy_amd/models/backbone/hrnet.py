@@ -36,7 +36,7 @@ BN_MOMENTUM = 0.1
 DEFAULT_CONV_ALGO = 'winograd4'
 DEFAULT_WINO4_MIN_HW = 7
 DEFAULT_WINO4_N64 = '0'
-DEFAULT_FUSE_ADD = '0'
+DEFAULT_FUSE_ADD = '0'          # 0 | 1 | 2 (HighResolutionNet.fuse_add)
 
 
 # ------------------------------------------------------------------------------------------
@@ -252,7 +252,7 @@ class _Plan:
             t = len(self.ops)
             if kw['group'] > 1:
                 self._group_left, self._group_t = kw['group'] - 1, t
-        for key in ('inb', 'outb', 'resb', 'inb2', 'inb3'):
+        for key in ('inb', 'outb', 'resb', 'inb2', 'inb3', 'inb4'):
             b = kw.get(key)
             if b is not None:
                 b.uses.append((self.epoch, kw['lane'], t))
@@ -260,7 +260,7 @@ class _Plan:
         # residual: the output's slice), write-after-read / -write on the slice written
         i, deps = len(self.ops), set()
         acc = []
-        for key in ('inb', 'inb2', 'inb3'):          # (inb2 / inb3: the further terms of a FUSEADD op)
+        for key in ('inb', 'inb2', 'inb3', 'inb4'):  # (inb2 .. inb4: the further terms of a FUSEADD op)
             if kw.get(key) is not None:
                 acc.append((kw[key], False, 0, kw[key].C))
         if kw.get('resb') is not None:
@@ -503,7 +503,16 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: lane, a 20 us job by traffic) after the GPU budget was spent: OFF until it has run on
         #: hardware (tests/test_zz_fuse_add_gpu.py is its first run; the plan and its arithmetic are
         #: checked on the CPU by tests/test_plan_replay.py)
-        self.fuse_add = os.environ.get('SHAPY_FUSE_ADD', DEFAULT_FUSE_ADD) == '1'
+        #: 2 (event-driven plans only) additionally takes x_i out of the accumulation: the stride-2
+        #: terms of output i are accumulated into a buffer of their own in the order their sources
+        #: become ready (x0 last), on lanes that are idle by then (fuse_chain_lanes, per stage:
+        #: 'dest' = the lane of the output, 'source' = the lane of the input branch, 'mixed' = dest
+        #: except for the last branch), and out_i = relu(x_i + T_i + upsample terms) is ONE short add
+        #: behind the last branch to finish -- in the traces the 7x7 lane of a stage-4 module ends last
+        #: and then runs 155-210 us of accumulating convs that had their inputs long before
+        #: (profiles/r04o_timeline_*_verbose.txt).  Same status as 1: CPU-checked, not yet run.
+        self.fuse_add = int(os.environ.get('SHAPY_FUSE_ADD', DEFAULT_FUSE_ADD))
+        self.fuse_chain_lanes = os.environ.get('SHAPY_FUSE_CHAIN_LANES', 'dest,dest,mixed')
 
         #: conv_algo='winograd4': the convs at the same depth of a HighResolutionModule's parallel
         #: branches as ONE persistent grouped launch (csrc/conv_wino4g.hip) instead of one launch
@@ -773,7 +782,50 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 x, Hc, Wc = conv(s[0], s[1], x, Hc, Wc, relu=True, lane=lane, name=f'{name}.{q}')
             return x, Hc, Wc
 
-        def module(m, xs, last_out=None, name=''):
+        def fuse_deferred(m, ys, last_out, name, stage):
+            """fuse_add = 2: out_i = relu(x_i + T_i + sum_{j>i} up(y_ij)); T_i = the stride-2 terms of
+            output i accumulated in a buffer of their own, sources in the order they become ready."""
+            nb = m.num_branches
+            pol = (self.fuse_chain_lanes.split(',') + ['dest'] * 3)[stage]
+            if pol not in ('dest', 'source', 'mixed'):
+                raise ValueError(f'fuse_chain_lanes: unknown policy {pol!r}')
+            low = {}
+            for i in range(nb):
+                for j in range(i + 1, nb):
+                    xj, Hj, Wj = ys[j]
+                    fl = m.fuse_layers[i][j]
+                    low[(i, j)], _, _ = conv(fl[0], fl[1], xj, Hj, Wj, lane=j,
+                                             name=f'{name}.fuse_layers.{i}.{j}')
+            T, started = {i: P.buf(ys[i][1], ys[i][2], ys[i][0].C) for i in range(1, nb)}, set()
+            for j in range(nb - 2, -1, -1):          # sources: the small maps first, x0 last
+                for i in range(j + 1, nb):
+                    lane = i if (pol == 'dest' or (pol == 'mixed' and i < nb - 1)) else j
+                    fl = m.fuse_layers[i][j]
+                    t, Ht, Wt = ys[j]
+                    for k in range(i - j - 1):
+                        t, Ht, Wt = conv(fl[k][0], fl[k][1], t, Ht, Wt, relu=True, lane=lane,
+                                         name=f'{name}.fuse_layers.{i}.{j}.{k}')
+                    k = i - j - 1
+                    conv(fl[k][0], fl[k][1], t, Ht, Wt, outb=T[i], res=T[i] if i in started else None,
+                         relu=False, lane=lane, name=f'{name}.fuse_layers.{i}.{j}.{k}')
+                    started.add(i)
+            outs = []
+            for i in range(nb):
+                xi, Hi_, Wi_ = ys[i]
+                use_last = last_out is not None and i == nb - 1
+                outb = last_out[0] if use_last else P.buf(Hi_, Wi_, xi.C)
+                o_ld = last_out[1] if use_last else xi.C
+                o_co = last_out[2] if use_last else 0
+                ups_terms = [low[(i, j)] for j in range(i + 1, nb)] + [None] * 3
+                P.op(type=_lib.OP_FUSEADD, lane=i, inb=ups_terms[0], inb2=ups_terms[1],
+                     inb3=ups_terms[2], inb4=T.get(i), outb=outb, resb=xi, Hi=Hi_, Wi=Wi_, Cin=xi.C,
+                     in_ld=xi.C, Ho=Hi_, Wo=Wi_, Cout=xi.C, ksize=nb - 1 - i, stride=1, pad=0,
+                     out_ld=o_ld, out_coff=o_co, res_ld=xi.C, res_coff=0, relu=1, ups=2, tile=0,
+                     wgt_off=-1, bias_off=-1, wino_off=-1, name=f'{name}.fuse_add.{i}')
+                outs.append((outb, Hi_, Wi_))
+            return outs
+
+        def module(m, xs, last_out=None, name='', stage=0):
             """xs: list of (buf, H, W).  HighResolutionModule.forward (hrnet.py:175-193)."""
             nb = m.num_branches
             ys = []
@@ -823,6 +875,11 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             dag = self._dag_eff and not grouped
             if not dag:
                 P.barrier()
+            fadd = int(self.fuse_add)
+            if fadd == 2 and not dag:
+                fadd = 1                    # (the deferred form needs the event-driven plan)
+            if fadd == 2:
+                return fuse_deferred(m, ys, last_out, name, stage)
             aux = [0]
             lead = {}                       # (i, j) -> (tensor, H, W) behind the chain's leading convs
             if dag:
@@ -858,7 +915,6 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             # they run as soon as that branch is done -- and added in one pass over the output
             # (OP_FUSEADD) instead of one upsample-scatter conv per term, each of which re-reads and
             # re-writes the whole output from the few workgroups of a low-resolution GEMM
-            fadd = bool(self.fuse_add) and not grouped
             low = {}                        # (i, j) -> low-resolution term y_ij
             if fadd:
                 for i in range(len(m.fuse_layers)):
@@ -936,7 +992,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                     Hl, Wl = ys[-1][1], ys[-1][2]
                     cat = P.buf(Hl, Wl, 4 * 384)
                     last = (cat, 4 * 384, 3 * 384)
-                ys = module(m, ys, last_out=last, name=f'stage{si + 2}.{mi}')
+                ys = module(m, ys, last_out=last, name=f'stage{si + 2}.{mi}', stage=si)
             if trans is not None:
                 P.barrier()
                 nxt = []
@@ -991,7 +1047,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             self._engine_ver = ver
         key = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
                self.wino4_min_hw, self._group_on(), self._dag_eff, self.dag_aux, self.dag_no_barriers, self.dag_balance,
-               self.wino4_n64, self.wino4_n64_min_hw, bool(self.fuse_add),
+               self.wino4_n64, self.wino4_n64_min_hw, int(self.fuse_add), self.fuse_chain_lanes,
                tuple(sorted(self.layer_algo.items())),
                self.tile_flags, tuple(sorted(self.tile_overrides.items())))
         eng = self._engine.get(key)
@@ -1010,12 +1066,13 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 setattr(a, f, int(o[f]))
             for q in range(3):
                 a.wait[q] = int(o['wait'][q])
-            a.in_off = -2 if o['type'] == _lib.OP_STEM else o['inb'].off
+            a.in_off = (-2 if o['type'] == _lib.OP_STEM else -1 if o['inb'] is None else o['inb'].off)
             a.out_off = -1 if o['outb'] is None else o['outb'].off
             a.res_off = -1 if o['resb'] is None else o['resb'].off
-            if o['type'] == _lib.OP_FUSEADD:      # terms 2 / 3 travel in the weight-offset fields
+            if o['type'] == _lib.OP_FUSEADD:      # the further terms travel in the weight-offset fields
                 a.wgt_off = -1 if o.get('inb2') is None else o['inb2'].off
                 a.bias_off = -1 if o.get('inb3') is None else o['inb3'].off
+                a.wino_off = -1 if o.get('inb4') is None else o['inb4'].off
         blob = np.frombuffer(b''.join(P.wchunks), dtype=np.uint8)
         weights = torch.from_numpy(blob.copy()).to(device)
         eng = dict(ops=arr, n_ops=n, weights=weights, ws_per_img=ws_per_img, plan=P, ws=None,

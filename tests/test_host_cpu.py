@@ -141,7 +141,11 @@ def _executor_order(ops):
 
 @pytest.mark.parametrize('dag,group,aux', [(True, False, False), (True, False, True), (True, False, 'nobar'),
                                            (False, False, False), (False, True, False),
-                                           (True, False, 'fuse_add'), (False, False, 'fuse_add')])
+                                           (True, False, 'fuse_add'), (False, False, 'fuse_add'),
+                                           (False, True, 'fuse_add'),
+                                           (True, False, 'fuse_add2:dest,dest,mixed'),
+                                           (True, False, 'fuse_add2:source,source,source'),
+                                           (True, False, 'fuse_add2:dest,dest,dest')])
 def test_plan_orders_every_memory_hazard(hrnet, dag, group, aux):
     """The executor's order (lanes, barriers, dependency events, launch groups) covers every hazard
     of the PACKED workspace: whenever two ops touch overlapping memory and at least one of them
@@ -151,25 +155,32 @@ def test_plan_orders_every_memory_hazard(hrnet, dag, group, aux):
     try:
         hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw = dag, group, 'winograd4', 7
         hrnet.dag_aux, hrnet.dag_no_barriers = aux is True, aux == 'nobar'
-        hrnet.fuse_add = aux == 'fuse_add'
+        hrnet.fuse_add = 1 if aux == 'fuse_add' else 2 if str(aux).startswith('fuse_add2') else 0
+        keep_lanes = hrnet.fuse_chain_lanes
+        if hrnet.fuse_add == 2:
+            hrnet.fuse_chain_lanes = aux.split(':')[1]
         P = hrnet._build_plan(224, 224)
         waits = P.sync_plan()
         total = P.allocate()
     finally:
-        hrnet.dag_aux = hrnet.dag_no_barriers = hrnet.fuse_add = False
+        hrnet.dag_aux = hrnet.dag_no_barriers = False
+        hrnet.fuse_add = 0
+        hrnet.fuse_chain_lanes = keep_lanes
         hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw = keep
-    if aux == 'fuse_add':
-        assert sum(1 for o in P.ops if o['type'] == 3) == 18 and not any(o['ups'] > 1 for o in P.ops if o['type'] == 0)
+    if str(aux).startswith('fuse_add'):
+        assert sum(1 for o in P.ops if o['type'] == 3) == (18 if aux == 'fuse_add' else 26)
+        assert not any(o['ups'] > 1 for o in P.ops if o['type'] == 0)
     ops = P.ops
     reach = _executor_order(ops)
     if dag:
-        assert sum(1 for w in waits if w) > 50 and sum(o['barrier_before'] for o in ops) < 20
+        assert sum(1 for w in waits if w) > 30 and sum(o['barrier_before'] for o in ops) < 20
     if aux == 'nobar':
         assert sum(o['barrier_before'] for o in ops) == 0
     # memory accesses: (op, write?, first float, end float, channel window inside a pixel row)
     acc = []
     for i, o in enumerate(ops):
         for key, is_w, c0, cn in (('inb', False, 0, None), ('inb2', False, 0, None), ('inb3', False, 0, None),
+                                  ('inb4', False, 0, None),
                                   ('resb', False, o['res_coff'], o['Cout']),
                                   ('outb', True, o['out_coff'], o['Cout'])):
             b = o.get(key)
@@ -196,7 +207,7 @@ def test_plan_orders_every_memory_hazard(hrnet, dag, group, aux):
     assert total * 4 / 1e6 < 20.0            # MB per 224x224 image: packing works (no reuse: 112 MB)
 
 
-@pytest.mark.parametrize('size,fuse_add', [(64, False), (256, False), (64, True), (256, True)])
+@pytest.mark.parametrize('size,fuse_add', [(64, 0), (256, 0), (64, 1), (256, 1), (64, 2), (256, 2)])
 def test_event_driven_plan_at_other_input_sizes(hrnet, size, fuse_add):
     """The dependency events fit their 64 slots and at most three waits per op at the sizes the
     reference uses besides 224 (256: expose configs; 64: the smallest legal input), and the
@@ -209,13 +220,14 @@ def test_event_driven_plan_at_other_input_sizes(hrnet, size, fuse_add):
         total = P.allocate()
     finally:
         hrnet._dag_eff, hrnet.conv_algo = keep
-        hrnet.fuse_add = False
+        hrnet.fuse_add = 0
     ops = P.ops
     assert max(len(w) for w in waits) <= 3 and max(o['sig'] for o in ops) < 64
     reach = _executor_order(ops)
     spans = []
     for i, o in enumerate(ops):
-        for key, is_w in (('inb', False), ('inb2', False), ('inb3', False), ('resb', False), ('outb', True)):
+        for key, is_w in (('inb', False), ('inb2', False), ('inb3', False), ('inb4', False), ('resb', False),
+                          ('outb', True)):
             b = o.get(key)
             if b is not None:
                 spans.append((i, is_w, b.off, b.off + b.size, id(b)))

@@ -64,6 +64,8 @@ def replay(eng, x):
             n_pix = a.Ho * a.Wo
             y = rows(a.res_off, n_pix, a.res_ld)[:, a.res_coff:a.res_coff + a.Cout].reshape(
                 B, a.Ho, a.Wo, a.Cout).clone()
+            if a.wino_off >= 0:                         # second full-resolution term (fuse_add = 2)
+                y = y + rows(a.wino_off, n_pix, a.Cout).reshape(B, a.Ho, a.Wo, a.Cout)
             for t, off in enumerate((a.in_off, a.wgt_off, a.bias_off)[:a.ksize]):
                 f = 2 << t
                 assert off >= 0 and a.Ho % f == 0 and a.Wo % f == 0
@@ -95,21 +97,32 @@ def seeded():
     return net, x, ref
 
 
-@pytest.mark.parametrize('dag,fuse_add', [(True, False), (True, True), (False, True)])
-def test_compiled_plan_replayed_on_the_cpu_equals_the_oracle(seeded, dag, fuse_add):
+@pytest.mark.parametrize('dag,fuse_add,lanes', [(True, 0, None), (True, 1, None), (False, 1, None),
+                                                ('grouped', 1, None),
+                                                (True, 2, 'dest,dest,mixed'), (True, 2, 'source,source,source'),
+                                                (True, 2, 'dest,dest,dest'), (False, 2, None)])
+def test_compiled_plan_replayed_on_the_cpu_equals_the_oracle(seeded, dag, fuse_add, lanes):
     net, x, ref = seeded
-    keep = net.dag, net.fuse_add, net.multi_stream
+    keep = net.dag, net.fuse_add, net.multi_stream, net.fuse_chain_lanes, net.group_branches, net.conv_algo
     try:
-        net.dag, net.fuse_add, net.multi_stream = dag, fuse_add, True
+        net.dag, net.fuse_add, net.multi_stream = bool(dag), fuse_add, True
+        if dag == 'grouped':       # persistent launch groups per depth level (needs the F(4x4) layers)
+            net.group_branches, net.conv_algo = True, 'winograd4'
+        if lanes:
+            net.fuse_chain_lanes = lanes
         eng = net._compile(64, 64, torch.device('cpu'))
     finally:
-        net.dag, net.fuse_add, net.multi_stream = keep
+        net.dag, net.fuse_add, net.multi_stream, net.fuse_chain_lanes, net.group_branches, net.conv_algo = keep
     from shapy_amd import _lib
     n_add = sum(1 for a in eng['ops'][:eng['n_ops']] if a.type == _lib.OP_FUSEADD)
     n_ups = sum(1 for a in eng['ops'][:eng['n_ops']] if a.type == _lib.OP_CONV and a.ups > 1)
-    # upsample terms of W48: stage 2: 1, stage 3: 4 x 3, stage 4: 3 x 6; outputs with such terms: 1 + 8 + 9
-    assert (n_add, n_ups) == ((18, 0) if fuse_add else (0, 31))
-    assert eng['n_ops'] == (332 + 18 if fuse_add else 332)
+    # upsample terms of W48: stage 2: 1, stage 3: 4 x 3, stage 4: 3 x 6; outputs with such terms: 1 + 8 + 9;
+    # all outputs: 2 + 12 + 12
+    deferred = fuse_add == 2 and dag is True           # (barrier plans fall back to form 1)
+    if dag == 'grouped':
+        assert sum(1 for a in eng['ops'][:eng['n_ops']] if a.group > 1) >= 8      # (64 x 64: stage 2 only)
+    assert (n_add, n_ups) == ((26, 0) if deferred else (18, 0) if fuse_add else (0, 31))
+    assert eng['n_ops'] == 332 + n_add
     with torch.no_grad():
         feats = replay(eng, x)
     assert feats.shape == ref.shape and torch.isfinite(feats).all()

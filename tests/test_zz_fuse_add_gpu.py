@@ -51,19 +51,22 @@ def _features(bb, x, **opts):
     return out[0]
 
 
+@pytest.mark.parametrize('form,lanes', [(1, None), (2, 'dest,dest,mixed'), (2, 'source,source,source')])
 @pytest.mark.parametrize('B,size,algo,multi', [(2, 64, 'direct', True), (3, 96, 'direct', False),
                                                (3, 224, 'winograd4', True), (2, 256, 'winograd4', True),
                                                (64, 224, 'winograd4', True)])
-def test_fuse_add_plan_equals_the_scatter_plan(backbone, B, size, algo, multi):
-    """Same convolutions, same order of the additions (base + up2 + up4 + up8): the features of the
-    fuse_add plan equal those of the upsample-scatter plan to rounding of the low-resolution 1x1 convs
-    (which may take another tile than their scatter form) -- 1e-5 of the feature scale."""
+def test_fuse_add_plan_equals_the_scatter_plan(backbone, B, size, algo, multi, form, lanes):
+    """Same convolutions; form 1: same order of the additions (base + up2 + up4 + up8), form 2: the
+    stride-2 terms summed apart from x_i (another association of the same sum): the features of the
+    fuse_add plans equal those of the upsample-scatter plan to rounding -- 1e-5 of the feature scale."""
     from shapy_amd.utils import synthetic as syn
     x = torch.from_numpy(syn.synthetic_images(B, size, 31)).cuda()
-    ref = _features(backbone, x, fuse_add=False, conv_algo=algo, multi_stream=multi)
-    got = _features(backbone, x, fuse_add=True, conv_algo=algo, multi_stream=multi)
-    plan = [e for k, e in backbone._engine.items() if k[0] == size and k[14] is True]
-    assert any(sum(1 for o in e['plan'].ops if o['type'] == 3) == 18 for e in plan)
+    ref = _features(backbone, x, fuse_add=0, conv_algo=algo, multi_stream=multi)
+    opts = dict(fuse_chain_lanes=lanes) if lanes else {}
+    got = _features(backbone, x, fuse_add=form, conv_algo=algo, multi_stream=multi, **opts)
+    plan = [e for k, e in backbone._engine.items() if k[0] == size and k[14] == form]
+    n_add = 26 if (form == 2 and multi) else 18          # (single-stream forwards fall back to form 1)
+    assert any(sum(1 for o in e['plan'].ops if o['type'] == 3) == n_add for e in plan)
     scale = ref.abs().max().item()
     err = (got - ref).abs().max().item()
     print(f'fuse_add vs scatter plan: B={B} {size}x{size} {algo}: scale {scale:.3g}, max diff {err:.2e}')
@@ -74,7 +77,7 @@ def test_fuse_add_features_vs_cpu_oracle(backbone):
     from oracle import hrnet_torch
     from shapy_amd.utils import synthetic as syn
     x = torch.from_numpy(syn.synthetic_images(2, 96, 32)).cuda()
-    got = _features(backbone, x, fuse_add=True, conv_algo='direct', multi_stream=True).cpu()
+    got = _features(backbone, x, fuse_add=2, conv_algo='direct', multi_stream=True).cpu()
     sd = {'backbone.' + k: v.detach().cpu() for k, v in backbone.state_dict().items()}
     torch.set_num_threads(min(torch.get_num_threads(), 32))
     with torch.no_grad():
@@ -87,9 +90,9 @@ def test_fuse_add_bf16_storage(backbone):
     form adds the float32 accumulator) -- a bf16-sized difference, bounded by the bf16 plan's own error."""
     from shapy_amd.utils import synthetic as syn
     x = torch.from_numpy(syn.synthetic_images(4, 224, 33)).cuda()
-    ref32 = _features(backbone, x, fuse_add=False, compute_dtype='f32', conv_algo='direct', multi_stream=True)
-    ref = _features(backbone, x, fuse_add=False, compute_dtype='bf16', multi_stream=True)
-    got = _features(backbone, x, fuse_add=True, compute_dtype='bf16', multi_stream=True)
+    ref32 = _features(backbone, x, fuse_add=0, compute_dtype='f32', conv_algo='direct', multi_stream=True)
+    ref = _features(backbone, x, fuse_add=0, compute_dtype='bf16', multi_stream=True)
+    got = _features(backbone, x, fuse_add=2, compute_dtype='bf16', multi_stream=True)
     e_ref = (ref.float() - ref32).abs().max().item()
     e_got = (got.float() - ref32).abs().max().item()
     print(f'bf16 error vs f32: scatter plan {e_ref:.3g}, fuse_add plan {e_got:.3g}')

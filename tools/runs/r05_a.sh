@@ -17,9 +17,16 @@ for rep in 1 2 3; do for v in "" variants/libtok3.so variants/libtok6.so; do
   if [ -n "$v" ]; then export SHAPY_HIP_LIB=$PWD/shapy_amd/csrc/$v; else unset SHAPY_HIP_LIB; fi
   echo "rep $rep ${v:-product}: $(timeout 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-also 2>/dev/null | grep '^{' | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "img/s", round(d["roofline"]["ms_per_launch_group"],3), "ms backbone")')"
 done; done 2>&1 | tee $O/token_bench.txt
-# --- second prepared experiment: the fuse_add plans (HighResolutionNet.fuse_add) ---
+# --- second prepared experiment: the fuse_add plans (HighResolutionNet.fuse_add = 1 | 2) ---
 unset SHAPY_HIP_LIB
-timeout 600 python -m pytest tests/test_zz_fuse_add_gpu.py -q -rA 2>&1 | tail -15 | tee $O/fuse_add_tests.txt
-for rep in 1 2 3; do for fa in off on; do
-  echo "rep $rep fuse_add $fa: $(timeout 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-also --fuse-add $fa 2>/dev/null | grep '^{' | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "img/s", round(d["roofline"]["ms_per_launch_group"],3), "ms backbone")')"
-done; done 2>&1 | tee $O/fuse_add_bench.txt
+timeout 900 python -m pytest tests/test_zz_fuse_add_gpu.py -q -rA 2>&1 | tail -30 | tee $O/fuse_add_tests.txt
+bench1() { timeout 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-also "$@" 2>/dev/null | grep '^{' | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "img/s", round(d["roofline"]["ms_per_launch_group"],3), "ms backbone")'; }
+for rep in 1 2 3; do
+  echo "rep $rep fuse_add 0: $(bench1 --fuse-add 0)"
+  echo "rep $rep fuse_add 1: $(bench1 --fuse-add 1)"
+  echo "rep $rep fuse_add 2 dest,dest,mixed: $(bench1 --fuse-add 2 --fuse-chain-lanes dest,dest,mixed)"
+  echo "rep $rep fuse_add 2 dest,dest,dest: $(bench1 --fuse-add 2 --fuse-chain-lanes dest,dest,dest)"
+  echo "rep $rep fuse_add 2 source,source,source: $(bench1 --fuse-add 2 --fuse-chain-lanes source,source,source)"
+  echo "rep $rep fuse_add 1 + launch groups: $(bench1 --fuse-add 1 --group-branches on)"
+done 2>&1 | tee $O/fuse_add_bench.txt
+# the winner's timeline: rocprofv3 --kernel-trace --stats --output-format csv ... then tools/timeline.py --verbose
