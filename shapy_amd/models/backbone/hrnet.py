@@ -503,7 +503,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: lane, a 20 us job by traffic) after the GPU budget was spent: OFF until it has run on
         #: hardware (tests/test_zz_fuse_add_gpu.py is its first run; the plan and its arithmetic are
         #: checked on the CPU by tests/test_plan_replay.py)
-        #: 2 (event-driven plans only) additionally takes x_i out of the accumulation: the stride-2
+        #: 2 additionally takes x_i out of the accumulation: the stride-2
         #: terms of output i are accumulated into a buffer of their own in the order their sources
         #: become ready (x0 last), on lanes that are idle by then (fuse_chain_lanes, per stage:
         #: 'dest' = the lane of the output, 'source' = the lane of the input branch, 'mixed' = dest
@@ -876,9 +876,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             if not dag:
                 P.barrier()
             fadd = int(self.fuse_add)
-            if fadd == 2 and not dag:
-                fadd = 1                    # (the deferred form needs the event-driven plan)
-            if fadd == 2:
+            if fadd == 2:                   # (cross-lane order by dependency events in every kind of plan)
                 return fuse_deferred(m, ys, last_out, name, stage)
             aux = [0]
             lead = {}                       # (i, j) -> (tensor, H, W) behind the chain's leading convs

@@ -145,7 +145,9 @@ def _executor_order(ops):
                                            (False, True, 'fuse_add'),
                                            (True, False, 'fuse_add2:dest,dest,mixed'),
                                            (True, False, 'fuse_add2:source,source,source'),
-                                           (True, False, 'fuse_add2:dest,dest,dest')])
+                                           (True, False, 'fuse_add2:dest,dest,dest'),
+                                           (False, False, 'fuse_add2:dest,dest,mixed'),
+                                           (False, True, 'fuse_add2:dest,dest,mixed')])
 def test_plan_orders_every_memory_hazard(hrnet, dag, group, aux):
     """The executor's order (lanes, barriers, dependency events, launch groups) covers every hazard
     of the PACKED workspace: whenever two ops touch overlapping memory and at least one of them

@@ -100,7 +100,8 @@ def seeded():
 @pytest.mark.parametrize('dag,fuse_add,lanes', [(True, 0, None), (True, 1, None), (False, 1, None),
                                                 ('grouped', 1, None),
                                                 (True, 2, 'dest,dest,mixed'), (True, 2, 'source,source,source'),
-                                                (True, 2, 'dest,dest,dest'), (False, 2, None)])
+                                                (True, 2, 'dest,dest,dest'), (False, 2, None),
+                                                ('grouped', 2, None)])
 def test_compiled_plan_replayed_on_the_cpu_equals_the_oracle(seeded, dag, fuse_add, lanes):
     net, x, ref = seeded
     keep = net.dag, net.fuse_add, net.multi_stream, net.fuse_chain_lanes, net.group_branches, net.conv_algo
@@ -118,7 +119,7 @@ def test_compiled_plan_replayed_on_the_cpu_equals_the_oracle(seeded, dag, fuse_a
     n_ups = sum(1 for a in eng['ops'][:eng['n_ops']] if a.type == _lib.OP_CONV and a.ups > 1)
     # upsample terms of W48: stage 2: 1, stage 3: 4 x 3, stage 4: 3 x 6; outputs with such terms: 1 + 8 + 9;
     # all outputs: 2 + 12 + 12
-    deferred = fuse_add == 2 and dag is True           # (barrier plans fall back to form 1)
+    deferred = fuse_add == 2
     if dag == 'grouped':
         assert sum(1 for a in eng['ops'][:eng['n_ops']] if a.group > 1) >= 8      # (64 x 64: stage 2 only)
     assert (n_add, n_ups) == ((26, 0) if deferred else (18, 0) if fuse_add else (0, 31))

@@ -65,7 +65,7 @@ def test_fuse_add_plan_equals_the_scatter_plan(backbone, B, size, algo, multi, f
     opts = dict(fuse_chain_lanes=lanes) if lanes else {}
     got = _features(backbone, x, fuse_add=form, conv_algo=algo, multi_stream=multi, **opts)
     plan = [e for k, e in backbone._engine.items() if k[0] == size and k[14] == form]
-    n_add = 26 if (form == 2 and multi) else 18          # (single-stream forwards fall back to form 1)
+    n_add = 26 if form == 2 else 18
     assert any(sum(1 for o in e['plan'].ops if o['type'] == 3) == n_add for e in plan)
     scale = ref.abs().max().item()
     err = (got - ref).abs().max().item()

@@ -28,5 +28,6 @@ for rep in 1 2 3; do
   echo "rep $rep fuse_add 2 dest,dest,dest: $(bench1 --fuse-add 2 --fuse-chain-lanes dest,dest,dest)"
   echo "rep $rep fuse_add 2 source,source,source: $(bench1 --fuse-add 2 --fuse-chain-lanes source,source,source)"
   echo "rep $rep fuse_add 1 + launch groups: $(bench1 --fuse-add 1 --group-branches on)"
+  echo "rep $rep fuse_add 2 + launch groups: $(bench1 --fuse-add 2 --group-branches on)"
 done 2>&1 | tee $O/fuse_add_bench.txt
 # the winner's timeline: rocprofv3 --kernel-trace --stats --output-format csv ... then tools/timeline.py --verbose
