@@ -100,13 +100,13 @@ def seeded():
 @pytest.mark.parametrize('dag,fuse_add,lanes', [(True, 0, None), (True, 1, None), (False, 1, None),
                                                 ('grouped', 1, None),
                                                 (True, 2, 'dest,dest,mixed'), (True, 2, 'source,source,source'),
-                                                (True, 2, 'dest,dest,dest'), (False, 2, None),
                                                 ('grouped', 2, None)])
 def test_compiled_plan_replayed_on_the_cpu_equals_the_oracle(seeded, dag, fuse_add, lanes):
     net, x, ref = seeded
     keep = net.dag, net.fuse_add, net.multi_stream, net.fuse_chain_lanes, net.group_branches, net.conv_algo
     try:
         net.dag, net.fuse_add, net.multi_stream = bool(dag), fuse_add, True
+        net.conv_algo = 'direct'   # (the replay reads the direct weights: no need to transform 209 filters)
         if dag == 'grouped':       # persistent launch groups per depth level (needs the F(4x4) layers)
             net.group_branches, net.conv_algo = True, 'winograd4'
         if lanes:
