@@ -59,7 +59,7 @@ namespace shapy {
 // and the head's 512 -> 512; five waves of 256 registers leave room for ONE workgroup per CU, all four
 // SIMDs multiply and the staging wave shares one of them).
 #ifdef SHAPY_W4_TOKEN
-// A/B variant (never built into the product library; first GPU run of round 5, tools/runs/r05_a.sh).
+// A/B variant (never built into the product library; first GPU runs of round 5, tools/runs/r05_b.sh).
 // tools/prio_probe.hip showed that s_setprio does NOT arbitrate the matrix pipe between the two waves of a
 // SIMD (2,265 vs 2,297 us for the higher / lower priority, profiles/r04ab_prio_probe.txt), so the two
 // workgroups of a CU always share it, finish their multiply phases together and run their epilogues

@@ -1,27 +1,14 @@
 #!/bin/bash
-# Prepared at the end of round 4 for the FIRST GPU run of round 5: the per-CU matrix-pipe token of the F(4x4) kernel
-# (-DSHAPY_W4_TOKEN=<max chunks>: conv_wino4.hip).  Build the variants first (CPU, ~1 min each):
-#   for n in 3 6; do SHAPY_HIPCC_FLAGS="-DSHAPY_W4_TOKEN=$n" SHAPY_HIP_LIB=$PWD/shapy_amd/csrc/variants/libtok$n.so python -m shapy_amd.build; done
-# Model (profiles/r04w_*, r04ab_*): residents in phase 32 us per pair of 48-channel tasks, with the
-# multiply phases serialised 21-27 us.  Isolated targets: 48@56^2 50 -> <= 40 us, 96@28^2 39 -> <= 33 us.
+# Prepared at the end of round 4 for the FIRST GPU run of round 5: the fuse_add plans (HighResolutionNet.fuse_add =
+# 1 | 2; DESIGN section 8, profiles/r04o_module_tails.txt).  Written and CPU-verified (tests/test_plan_replay.py)
+# after round 4's GPU budget was spent; the kernel (csrc/hrnet_ops.hip: fuse_add_kernel) has never run.
+# Expected: stage-3 modules 1,000 -> ~850 us, stage-4 modules 1,450 -> 1,000-1,250 us (0.6-2 ms of the 12.4 ms step).
 set -u
 mkdir -p gpurun_out/r05a
-O=gpurun_out/r05a
-for v in "" variants/libtok3.so variants/libtok6.so; do
-  echo "=== lib ${v:-product}"
-  if [ -n "$v" ]; then export SHAPY_HIP_LIB=$PWD/shapy_amd/csrc/$v; else unset SHAPY_HIP_LIB; fi
-  timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "winograd4_kernel or winograd4_concat" 2>&1 | tail -1
-  timeout 200 python tools/conv_bench.py --tiles wino4 --iters 20 2>&1 | grep -E "wino4" | grep "r1\|256->" | cut -c1-100
-done 2>&1 | tee $O/token_classes.txt
-for rep in 1 2 3; do for v in "" variants/libtok3.so variants/libtok6.so; do
-  if [ -n "$v" ]; then export SHAPY_HIP_LIB=$PWD/shapy_amd/csrc/$v; else unset SHAPY_HIP_LIB; fi
-  echo "rep $rep ${v:-product}: $(timeout 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-also 2>/dev/null | grep '^{' | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "img/s", round(d["roofline"]["ms_per_launch_group"],3), "ms backbone")')"
-done; done 2>&1 | tee $O/token_bench.txt
-# --- second prepared experiment: the fuse_add plans (HighResolutionNet.fuse_add = 1 | 2) ---
-unset SHAPY_HIP_LIB
-timeout 900 python -m pytest tests/test_zz_fuse_add_gpu.py -q -rA 2>&1 | tail -30 | tee $O/fuse_add_tests.txt
-bench1() { timeout 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-also "$@" 2>/dev/null | grep '^{' | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "img/s", round(d["roofline"]["ms_per_launch_group"],3), "ms backbone")'; }
-for rep in 1 2 3; do
+O=$GRAFT_REPO_ROOT/gpurun_out/r05a
+timeout 900 python -m pytest tests/test_zz_fuse_add_gpu.py -q -rA 2>&1 | tail -40 | tee $O/fuse_add_tests.txt
+bench1() { timeout 300 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-also "$@" 2>/dev/null | grep '^{' | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],1), "img/s", round(d["roofline"]["ms_per_launch_group"],3), "ms backbone", "betas", (d.get("parity") or {}).get("betas_l2"))'; }
+for rep in 1 2; do
   echo "rep $rep fuse_add 0: $(bench1 --fuse-add 0)"
   echo "rep $rep fuse_add 1: $(bench1 --fuse-add 1)"
   echo "rep $rep fuse_add 2 dest,dest,mixed: $(bench1 --fuse-add 2 --fuse-chain-lanes dest,dest,mixed)"
@@ -30,4 +17,13 @@ for rep in 1 2 3; do
   echo "rep $rep fuse_add 1 + launch groups: $(bench1 --fuse-add 1 --group-branches on)"
   echo "rep $rep fuse_add 2 + launch groups: $(bench1 --fuse-add 2 --group-branches on)"
 done 2>&1 | tee $O/fuse_add_bench.txt
-# the winner's timeline: rocprofv3 --kernel-trace --stats --output-format csv ... then tools/timeline.py --verbose
+# where the time goes in each form: kernel trace -> per-op timeline -> per-module lane starts / ends / tails
+cd /tmp; export TMPDIR=/tmp
+for v in "0" "1" "2 --fuse-chain-lanes dest,dest,mixed"; do
+  tag=$(echo $v | cut -c1)
+  rm -rf $O/prof$tag
+  timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/prof$tag -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-also --fuse-add $v > /dev/null 2>&1
+  ( cd $GRAFT_REPO_ROOT; timeout 200 python tools/timeline.py $O/prof$tag --verbose --fuse-add $v > $O/timeline_fuse_add_$tag.txt 2>$O/timeline_$tag.err
+    python tools/module_tails.py $O/timeline_fuse_add_$tag.txt | tee $O/module_tails_fuse_add_$tag.txt )
+  rm -rf $O/prof$tag
+done
