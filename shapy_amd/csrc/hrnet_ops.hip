@@ -246,6 +246,8 @@ constexpr int N_SIDE = 6;        // side streams: lanes 1..3 = branches, 4..6 = 
 constexpr int N_EVENTS = 64;     // dependency events (ShapyOp.sig / .wait), reused from epoch to epoch
 struct Lanes {
   hipStream_t s[N_SIDE] = {};
+  hipStream_t s0 = nullptr;        // SHAPY_LANE_CU_EIGHTHS experiment: lane 0 on a CU-masked stream of its own
+  hipEvent_t s0_in = nullptr, s0_out = nullptr;
   hipEvent_t fork = nullptr;
   hipEvent_t join[N_SIDE] = {};
   hipEvent_t ev[N_EVENTS] = {};
@@ -259,10 +261,39 @@ static std::mutex g_lanes_mu;
 // (SHAPY_LANE_PRIO=0 turns the priorities off; +1.1..1.6 % end to end, run T of round 3) lane i + 1
 // (the branch with the smaller maps = the longer chain of latency-bound launches) gets a higher
 // stream priority than lane i.
+// EXPERIMENT (off unless SHAPY_LANE_CU_EIGHTHS is set; prepared at the end of round 4, never run):
+// "a,b,c,d" = how many eighths of the CUs the streams of lanes 0..3 may use (residue classes of the CU
+// index mod 8, handed out in this order; 0 = no mask).  In the traces the first launch of a small-map
+// lane waits 160-300 us for workgroup slots that the two large lanes' launches keep refilling
+// (profiles/r04o_module_tails.txt); a partition gives every lane slots of its own.  With a share for
+// lane 0 the executor runs lane 0 on an internal masked stream between a fork from and a join to the
+// caller's stream.  Masked streams carry no stream priority.
+static int lane_cu_share(int lane, uint32_t (&mask)[8]) {
+  static const char *env = getenv("SHAPY_LANE_CU_EIGHTHS");
+  if (!env || lane > 3) return 0;
+  int share[4] = {0, 0, 0, 0};
+  if (sscanf(env, "%d,%d,%d,%d", &share[0], &share[1], &share[2], &share[3]) < 1) return 0;
+  int first = 0;
+  for (int l = 0; l < lane; ++l) first += share[l] > 0 ? share[l] : 0;
+  const int n = share[lane];
+  if (n <= 0 || first + n > 8) return 0;
+  for (int w = 0; w < 8; ++w) {
+    mask[w] = 0;
+    for (int b = 0; b < 32; ++b) {
+      const int r = (w * 32 + b) & 7;
+      if (r >= first && r < first + n) mask[w] |= 1u << b;
+    }
+  }
+  return n;
+}
+
 static int lane_stream(Lanes *L, int li, hipStream_t *out) {
   if (!L->s[li]) {
     static const int prio_mode = getenv("SHAPY_LANE_PRIO") ? atoi(getenv("SHAPY_LANE_PRIO")) : 1;
-    if (prio_mode) {
+    uint32_t mask[8];
+    if (lane_cu_share(li + 1, mask)) {
+      SHAPY_HIP_TRY(hipExtStreamCreateWithCUMask(&L->s[li], 8, mask));
+    } else if (prio_mode) {
       int plo = 0, phi = 0;
       SHAPY_HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi));    // phi = highest (numerically lowest)
       int pr = plo - (li % 3 + 1);
@@ -310,6 +341,22 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
     int rc = get_lanes(&L);
     if (rc) return rc;
   }
+  // lane 0 = the caller's stream -- unless the CU-partition experiment gives lane 0 a share: then an
+  // internal masked stream that starts behind the caller's stream here and is joined to it at the end
+  hipStream_t caller = main;
+  if (multi_stream) {
+    uint32_t mask[8];
+    if (lane_cu_share(0, mask)) {
+      if (!L->s0) {
+        SHAPY_HIP_TRY(hipExtStreamCreateWithCUMask(&L->s0, 8, mask));
+        SHAPY_HIP_TRY(hipEventCreateWithFlags(&L->s0_in, hipEventDisableTiming));
+        SHAPY_HIP_TRY(hipEventCreateWithFlags(&L->s0_out, hipEventDisableTiming));
+      }
+      SHAPY_HIP_TRY(hipEventRecord(L->s0_in, caller));
+      SHAPY_HIP_TRY(hipStreamWaitEvent(L->s0, L->s0_in, 0));
+      main = L->s0;
+    }
+  }
   bool forked[N_SIDE] = {}, dirty[N_SIDE] = {};
   auto join_all = [&]() -> int {
     for (int i = 0; i < N_SIDE; ++i)
@@ -318,6 +365,13 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
         SHAPY_HIP_TRY(hipStreamWaitEvent(main, L->join[i], 0));
         dirty[i] = false;
       }
+    return SHAPY_OK;
+  };
+  auto leave = [&]() -> int {            // internal lane-0 stream -> the caller's stream
+    if (main != caller) {
+      SHAPY_HIP_TRY(hipEventRecord(L->s0_out, main));
+      SHAPY_HIP_TRY(hipStreamWaitEvent(caller, L->s0_out, 0));
+    }
     return SHAPY_OK;
   };
   bool fork_recorded = false;
@@ -412,7 +466,10 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
         rc = conv2d(d, s);
       }
       if (rc) {
-        if (multi_stream) join_all();        // leave no forked lane unjoined behind an error
+        if (multi_stream) {                  // leave no forked lane unjoined behind an error
+          join_all();
+          leave();
+        }
         return rc;
       }
     } else if (o.type == SHAPY_OP_STEM) {
@@ -480,6 +537,8 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
   }
   if (multi_stream) {
     int rc = join_all();
+    if (rc) return rc;
+    rc = leave();
     if (rc) return rc;
   }
   return SHAPY_OK;
