@@ -100,6 +100,7 @@ typedef struct ShapyConv {
                          loop chunk by chunk, 0x40000 / 0x80000 three / one chunk(s) of loads in
                          flight.  Speed only: every setting computes the same convolution.
                          (0x200000: F(4x4) kernel with its 12-chunk loop unrolled, Cin = 192;
+                         0x400000: F(4x4) on the 64-channel N tile when Cout % 64 == 0 too;
                          bits 24..30: F(4x4) kernels, start delay of a CU's second workgroup in
                          units of 128 clocks, SHAPY_TILE_W4_STAGGER(n).)
                          One bit describes DATA instead: SHAPY_TILE_WINO4 (0x100000) says that

@@ -71,6 +71,7 @@ for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: con
     TILES[_k + '+pd1'] = _v | 0x80000         # ... 1 chunk (float32 default)
     TILES[_k + '+noallk'] = _v | 0x20000      # Winograd: K loop chunk by chunk even for Cin = 48 / 64
 TILE_WINO4 = 0x100000                   # ShapyConv.wgt_wino holds F(4x4,3x3) filters (conv_wino4.hip)
+TILE_WINO4_N64 = 0x400000               # A/B knob: F(4x4) on the 64-channel N tile when Cout % 64 == 0 too (192, 384)
 TILE_WINO4_UNROLL12 = 0x200000          # A/B knob: F(4x4) kernel with its 12-chunk loop unrolled (Cin = 192)
 
 

@@ -48,6 +48,7 @@ struct ConvK {
   int pd3;                      // implicit GEMM: three chunks of global loads in flight
   int dbg;                      // -DSHAPY_WINO_TIMING builds only: ablation mask (wrong results)
   int w4_unroll12;              // tuning: F(4x4) kernel with the 12-chunk loop unrolled (Cin = 192)
+  int w4_n64;                   // tile flag 0x400000: F(4x4) on the 64-channel N tile when Cout % 64 == 0
   int w4_stagger;               // F(4x4): start delay of a CU's second workgroup, units of 128 clocks
 };
 

@@ -359,6 +359,7 @@ int conv_prepare(const ShapyConv &d, ConvK &k, int *empty) {
   k.no_allk = (d.tile & 0x20000) ? 1 : 0;
   k.dbg = 0;
   k.w4_unroll12 = 0;
+  k.w4_n64 = 0;
   k.w4_stagger = (d.tile >> 24) & 0x7f;       // F(4x4) kernels: SHAPY_TILE_W4_STAGGER(n)
   k.flat = flat ? 1 : 0;
   return SHAPY_OK;
@@ -380,6 +381,7 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   // kernel for that layout, so an ineligible layer is an error, not a fallback
   if (d.tile & 0x100000) {
     k.w4_unroll12 = (d.tile & 0x200000) ? 1 : 0;
+    k.w4_n64 = (d.tile & 0x400000) ? 1 : 0;
     if (conv_wino4_fits(k)) {      // (size limits first: conv_wino_eligible also refuses > 2 GiB)
       if (d.dtype != SHAPY_DTYPE_F32 || !conv_wino_eligible(k)) return SHAPY_EINVAL;
       return conv2d_wino4(k, s);

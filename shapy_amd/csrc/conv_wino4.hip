@@ -351,7 +351,10 @@ int conv2d_wino4(ConvK k, hipStream_t s) {
   const int B = k.M / (k.Ho * k.Wo);
   k.wino_tiles = B * ((k.Hi + 3) / 4) * ((k.Wi + 3) / 4);
   k.wgt2_bytes = (unsigned)(144ull * k.Cin * k.Cout);          // 36 positions x f32
-  const bool n64 = k.Cout % 48 != 0;                           // (conv_wino4_fits: then Cout % 64 == 0)
+  // 64-channel N tile (four multiplying waves, one workgroup per CU): layers whose Cout is no multiple of
+  // 48 (conv_wino4_fits: then Cout % 64 == 0), and on request (tile flag 0x400000, an A/B knob) those
+  // with BOTH -- 192 = 3 x 64, 384 = 6 x 64: all four SIMDs of a CU multiply
+  const bool n64 = k.Cout % 48 != 0 || (k.w4_n64 && k.Cout % 64 == 0);
   k.nbx = k.Cout / (n64 ? 64 : 48);
   k.nby = (k.wino_tiles + 15) / 16;
 #ifdef SHAPY_WINO_TIMING

@@ -496,6 +496,12 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: profiles/r04t_*), and on the head's 512 -> 512 @7x7 it loses (131 vs 100 us)
         self.wino4_n64 = os.environ.get('SHAPY_WINO4_N64', DEFAULT_WINO4_N64) == '1'
         self.wino4_n64_min_hw = int(os.environ.get('SHAPY_WINO4_N64_MIN_HW', '28'))
+        #: F(4x4) layers with these output widths (multiples of 48 AND of 64: 192, 384) on the
+        #: 64-channel N tile -- all four SIMDs of a CU multiply, one workgroup per CU, 25 % fewer
+        #: workgroups.  An A/B knob (SHAPY_WINO4_N64_COUT="192,384"), empty = off; prepared at the
+        #: end of round 4: in the stage-4 branch phases the chip runs at 82-85 % of what THREE
+        #: multiplying SIMDs per CU can do, the fourth is the next third
+        self.wino4_n64_cout = tuple(int(c) for c in os.environ.get('SHAPY_WINO4_N64_COUT', '').split(',') if c)
         #: the upsample terms of a fuse output (reference hrnet.py:181-191: 1x1 conv + BN + nearest
         #: Upsample, added to the output) as plain low-resolution convs + ONE add pass over the output
         #: (SHAPY_OP_FUSEADD) instead of one upsample-scatter conv per term.  Written at the end of
@@ -719,6 +725,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             elif not (bf16 or x6) and self._use_wino4(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
                 wino_off = P.add_weights(winograd.transform_filters4(w))
                 wino_flag = _lib.TILE_WINO4
+                if cout_p in self.wino4_n64_cout and cout_p % 64 == 0:
+                    wino_flag |= _lib.TILE_WINO4_N64
             elif not (bf16 or x6) and self._use_wino(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
                 wino_off = P.add_weights(winograd.transform_filters(w))
             # rough cost of the launch under the usual four-stream contention (us): picks the lane of
@@ -1046,6 +1054,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         key = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
                self.wino4_min_hw, self._group_on(), self._dag_eff, self.dag_aux, self.dag_no_barriers, self.dag_balance,
                self.wino4_n64, self.wino4_n64_min_hw, int(self.fuse_add), self.fuse_chain_lanes,
+               tuple(self.wino4_n64_cout),
                tuple(sorted(self.layer_algo.items())),
                self.tile_flags, tuple(sorted(self.tile_overrides.items())))
         eng = self._engine.get(key)

@@ -415,6 +415,20 @@ def test_winograd4_plan_filters_and_kernel_indexing(hrnet):
     emu.check(1, 14, 14, 16, 48, False, False, coff=16)  # channel-offset epilogue
 
 
+def test_forced_64_channel_tile_flag_marks_the_192_and_384_channel_layers(hrnet):
+    from shapy_amd import _lib
+    keep = hrnet.conv_algo, hrnet.wino4_n64_cout
+    try:
+        hrnet.conv_algo, hrnet.wino4_n64_cout = 'winograd4', (192, 384)
+        P = hrnet._build_plan(224, 224)
+    finally:
+        hrnet.conv_algo, hrnet.wino4_n64_cout = keep
+    w4 = [o for o in P.ops if o['type'] == 0 and o['tile'] & _lib.TILE_WINO4]
+    flagged = [o for o in w4 if o['tile'] & _lib.TILE_WINO4_N64]
+    assert len(w4) == 209 and {o['Cout'] for o in flagged} == {192, 384}
+    assert len(flagged) == sum(1 for o in w4 if o['Cout'] in (192, 384)) == 80
+
+
 def test_bench_flop_accounting_algorithmic_vs_executed(hrnet):
     """bench.py: `roofline.achieved` counts the direct-convolution FLOPs of SURVEY.md 8(d) whatever
     the algorithm; `executed_mfma` what the matrix cores run (F(2x2): 16 products per 2x2 tile,
