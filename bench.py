@@ -622,6 +622,35 @@ def also_records(args, net, x):
     return out
 
 
+def experimental_records(args):
+    """Opt-in plans that were written after the last GPU run of their round (HighResolutionNet.fuse_add):
+    each is timed by THIS script in a process of its own -- a fault in a path that has not run on
+    hardware yet must not cost the headline line -- with the same batch, 10 steps, and compared with the
+    default plan's forward of the same batch.  Compact records under `also`; an `error` entry otherwise."""
+    out = {}
+    for form in (1, 2):
+        tag = f'experimental_fuse_add_{form}'
+        try:
+            cmd = [sys.executable, osp.abspath(__file__), '--gpus', '1', '--steps', '10', '--warmup', '4',
+                   '--no-also', '--no-cpu-baseline', '--batch', str(args.batch), '--size', str(args.size),
+                   '--fuse-add', str(form), '--fuse-add-check']
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            if r.returncode != 0 or not lines:
+                out[tag] = {'error': f'rc {r.returncode}', 'stderr_tail': r.stderr[-400:]}
+                continue
+            d = json.loads(lines[-1])
+            out[tag] = {'metric': d['metric'], 'value': d['value'], 'unit': d['unit'],
+                        'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'dtype': d['dtype'],
+                        'workload': d['config']['workload'] + f', fuse_add = {form} (opt-in plan, own process)',
+                        'roofline': {k: d['roofline'][k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac',
+                                                                   'ms_per_launch_group')},
+                        'parity': d.get('fuse_add_check')}
+        except Exception as e:
+            out[tag] = {'error': repr(e)}
+    return out
+
+
 def run_regressor(args, rank, world, local_rank):
     """Returns (json dict or None, finish): `finish(res)` adds the rank-0 CPU oracle fields
     (cpu_baseline, parity) and is called by main() AFTER the process group is torn down, so no
@@ -848,8 +877,22 @@ def run_regressor(args, rank, world, local_rank):
                                'joined_by_next_step': gatherer.deferred_waits,
                                'note': 'world-size-1 RCCL communicator: the all_gather of the N-rank step on '
                                        'ONE GPU (work / side: through c10d, with its RCCL stream)'}
+    if getattr(args, 'fuse_add_check', False) and int(getattr(net.backbone, 'fuse_add', 0)):
+        # (after the timed region) the same batch through the fuse_add = 0 plan of the same network
+        fa = net.backbone.fuse_add
+        try:
+            net.backbone.fuse_add = 0
+            with torch.no_grad():
+                ref = net(x, None)
+            res['fuse_add_check'] = {
+                'reference': 'the fuse_add = 0 forward of the same network and batch (the headline path)',
+                'features_maxabs': float((out['features'] - ref['features']).abs().max()),
+                'betas_maxabs': float((out['stage_02']['betas'] - ref['stage_02']['betas']).abs().max())}
+        finally:
+            net.backbone.fuse_add = fa
     if world == 1 and not getattr(args, 'no_also', False) and not getattr(args, '_sub', False):
         res['also'] = also_records(args, net, x)
+        res['also'].update(experimental_records(args))
 
     def finish(res):                                 # rank 0 only; after destroy_process_group()
         if not args.no_cpu_baseline:
@@ -914,6 +957,7 @@ def main():
                     help='upsample terms of the fuse layers as low-resolution convs + one add pass (1 = on); '
                          '2: also the stride-2 terms accumulated apart from x_i, one short add per output '
                          '(HighResolutionNet.fuse_add; default: the backbone\'s own, 0)')
+    ap.add_argument('--fuse-add-check', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--fuse-chain-lanes', default=None,
                     help='with --fuse-add 2: lane policy of the stride-2 chains per stage, e.g. '
                          '"dest,dest,mixed" (HighResolutionNet.fuse_chain_lanes)')
