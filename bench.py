@@ -622,19 +622,25 @@ def also_records(args, net, x):
     return out
 
 
-def experimental_records(args):
-    """Opt-in plans that were written after the last GPU run of their round (HighResolutionNet.fuse_add):
-    each is timed by THIS script in a process of its own -- a fault in a path that has not run on
-    hardware yet must not cost the headline line -- with the same batch, 10 steps, and compared with the
-    default plan's forward of the same batch.  Compact records under `also`; an `error` entry otherwise."""
+def experimental_records(args, betas_sha1=None):
+    """Opt-in plans / executor modes that were written after the last GPU run of their round: each is
+    timed by THIS script in a process of its own -- a fault in a path that has not run on hardware yet
+    must not cost the headline line -- with the same batch, 8 steps, and compared with the default plan
+    (in that process: features / betas of the same batch with the knobs off; here: whether its betas are
+    bit-identical to the headline's).  Compact records under `also`; an `error` entry otherwise."""
     out = {}
-    for form in (1, 2):
-        tag = f'experimental_fuse_add_{form}'
+    todo = [('experimental_fuse_add_1', ['--fuse-add', '1'], {}, 'HighResolutionNet.fuse_add = 1'),
+            ('experimental_fuse_add_2', ['--fuse-add', '2'], {}, 'HighResolutionNet.fuse_add = 2'),
+            ('experimental_wino4_n64_192_384', [], {'SHAPY_WINO4_N64_COUT': '192,384'},
+             'F(4x4) 64-channel N tile on the 192- / 384-channel layers'),
+            ('experimental_lane_cu_partition_5111', [], {'SHAPY_LANE_CU_EIGHTHS': '5,1,1,1'},
+             'CU partition between the four lanes, 5/8 : 1/8 : 1/8 : 1/8')]
+    for tag, extra, env, what in todo:
         try:
-            cmd = [sys.executable, osp.abspath(__file__), '--gpus', '1', '--steps', '10', '--warmup', '4',
+            cmd = [sys.executable, osp.abspath(__file__), '--gpus', '1', '--steps', '8', '--warmup', '3',
                    '--no-also', '--no-cpu-baseline', '--batch', str(args.batch), '--size', str(args.size),
-                   '--fuse-add', str(form), '--fuse-add-check']
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                   '--check-vs-default'] + extra
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
             lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
             if r.returncode != 0 or not lines:
                 out[tag] = {'error': f'rc {r.returncode}', 'stderr_tail': r.stderr[-400:]}
@@ -642,10 +648,12 @@ def experimental_records(args):
             d = json.loads(lines[-1])
             out[tag] = {'metric': d['metric'], 'value': d['value'], 'unit': d['unit'],
                         'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'dtype': d['dtype'],
-                        'workload': d['config']['workload'] + f', fuse_add = {form} (opt-in plan, own process)',
+                        'workload': d['config']['workload'] + f'; {what} (opt-in, own process)',
                         'roofline': {k: d['roofline'][k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac',
                                                                    'ms_per_launch_group')},
-                        'parity': d.get('fuse_add_check')}
+                        'parity': dict(d.get('check_vs_default') or {},
+                                       betas_bit_identical_to_headline=(
+                                           None if betas_sha1 is None else d.get('betas_sha1') == betas_sha1))}
         except Exception as e:
             out[tag] = {'error': repr(e)}
     return out
@@ -877,22 +885,27 @@ def run_regressor(args, rank, world, local_rank):
                                'joined_by_next_step': gatherer.deferred_waits,
                                'note': 'world-size-1 RCCL communicator: the all_gather of the N-rank step on '
                                        'ONE GPU (work / side: through c10d, with its RCCL stream)'}
-    if getattr(args, 'fuse_add_check', False) and int(getattr(net.backbone, 'fuse_add', 0)):
-        # (after the timed region) the same batch through the fuse_add = 0 plan of the same network
-        fa = net.backbone.fuse_add
+    import hashlib
+    res['betas_sha1'] = hashlib.sha1(betas_host.numpy().tobytes()).hexdigest()[:16]
+    if getattr(args, 'check_vs_default', False):
+        # (after the timed region) the same batch through the DEFAULT plan of the same network: the
+        # in-process knobs off (fuse_add, the forced 64-channel tile); executor modes set through the
+        # environment stay as they are -- those must be bit-identical to the headline anyway
+        bb = net.backbone
+        keep = bb.fuse_add, bb.wino4_n64_cout
         try:
-            net.backbone.fuse_add = 0
+            bb.fuse_add, bb.wino4_n64_cout = 0, ()
             with torch.no_grad():
                 ref = net(x, None)
-            res['fuse_add_check'] = {
-                'reference': 'the fuse_add = 0 forward of the same network and batch (the headline path)',
+            res['check_vs_default'] = {
+                'reference': 'the default-plan forward of the same network and batch in the same process',
                 'features_maxabs': float((out['features'] - ref['features']).abs().max()),
                 'betas_maxabs': float((out['stage_02']['betas'] - ref['stage_02']['betas']).abs().max())}
         finally:
-            net.backbone.fuse_add = fa
+            bb.fuse_add, bb.wino4_n64_cout = keep
     if world == 1 and not getattr(args, 'no_also', False) and not getattr(args, '_sub', False):
         res['also'] = also_records(args, net, x)
-        res['also'].update(experimental_records(args))
+        res['also'].update(experimental_records(args, res.get('betas_sha1')))
 
     def finish(res):                                 # rank 0 only; after destroy_process_group()
         if not args.no_cpu_baseline:
@@ -957,7 +970,7 @@ def main():
                     help='upsample terms of the fuse layers as low-resolution convs + one add pass (1 = on); '
                          '2: also the stride-2 terms accumulated apart from x_i, one short add per output '
                          '(HighResolutionNet.fuse_add; default: the backbone\'s own, 0)')
-    ap.add_argument('--fuse-add-check', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--check-vs-default', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--fuse-chain-lanes', default=None,
                     help='with --fuse-add 2: lane policy of the stride-2 chains per stage, e.g. '
                          '"dest,dest,mixed" (HighResolutionNet.fuse_chain_lanes)')
