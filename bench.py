@@ -622,43 +622,6 @@ def also_records(args, net, x):
     return out
 
 
-def experimental_records(args, betas_sha1=None):
-    """Opt-in plans / executor modes that were written after the last GPU run of their round: each is
-    timed by THIS script in a process of its own -- a fault in a path that has not run on hardware yet
-    must not cost the headline line -- with the same batch, 8 steps, and compared with the default plan
-    (in that process: features / betas of the same batch with the knobs off; here: whether its betas are
-    bit-identical to the headline's).  Compact records under `also`; an `error` entry otherwise."""
-    out = {}
-    todo = [('experimental_fuse_add_1', ['--fuse-add', '1'], {}, 'HighResolutionNet.fuse_add = 1'),
-            ('experimental_fuse_add_2', ['--fuse-add', '2'], {}, 'HighResolutionNet.fuse_add = 2'),
-            ('experimental_wino4_n64_192_384', [], {'SHAPY_WINO4_N64_COUT': '192,384'},
-             'F(4x4) 64-channel N tile on the 192- / 384-channel layers'),
-            ('experimental_lane_cu_partition_5111', [], {'SHAPY_LANE_CU_EIGHTHS': '5,1,1,1'},
-             'CU partition between the four lanes, 5/8 : 1/8 : 1/8 : 1/8')]
-    for tag, extra, env, what in todo:
-        try:
-            cmd = [sys.executable, osp.abspath(__file__), '--gpus', '1', '--steps', '8', '--warmup', '3',
-                   '--no-also', '--no-cpu-baseline', '--batch', str(args.batch), '--size', str(args.size),
-                   '--check-vs-default'] + extra
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
-            lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-            if r.returncode != 0 or not lines:
-                out[tag] = {'error': f'rc {r.returncode}', 'stderr_tail': r.stderr[-400:]}
-                continue
-            d = json.loads(lines[-1])
-            out[tag] = {'metric': d['metric'], 'value': d['value'], 'unit': d['unit'],
-                        'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'dtype': d['dtype'],
-                        'workload': d['config']['workload'] + f'; {what} (opt-in, own process)',
-                        'roofline': {k: d['roofline'][k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac',
-                                                                   'ms_per_launch_group')},
-                        'parity': dict(d.get('check_vs_default') or {},
-                                       betas_bit_identical_to_headline=(
-                                           None if betas_sha1 is None else d.get('betas_sha1') == betas_sha1))}
-        except Exception as e:
-            out[tag] = {'error': repr(e)}
-    return out
-
-
 def run_regressor(args, rank, world, local_rank):
     """Returns (json dict or None, finish): `finish(res)` adds the rank-0 CPU oracle fields
     (cpu_baseline, parity) and is called by main() AFTER the process group is torn down, so no
@@ -679,7 +642,7 @@ def run_regressor(args, rank, world, local_rank):
                                  else '/tmp/shapy_synth_models')
         net.backbone.multi_stream = not args.single_stream
         net.backbone.compute_dtype = args.dtype
-        net.backbone.use_graph = {'auto': 'auto', 'on': True, 'off': False, 'explicit': 'explicit'}[args.graph]
+        net.backbone.use_graph = {'auto': 'auto', 'on': True, 'off': False}[args.graph]
         if args.algo:
             net.backbone.conv_algo = args.algo
         if args.wino4_min_hw:
@@ -688,10 +651,6 @@ def run_regressor(args, rank, world, local_rank):
             net.backbone.tile_flags = int(args.tile_flags, 0)
         if getattr(args, 'group_branches', None):
             net.backbone.group_branches = {'auto': 'auto', 'on': True, 'off': False}[args.group_branches]
-        if getattr(args, 'fuse_add', None):
-            net.backbone.fuse_add = {'off': 0, 'on': 1, '0': 0, '1': 1, '2': 2}[args.fuse_add]
-        if getattr(args, 'fuse_chain_lanes', None):
-            net.backbone.fuse_chain_lanes = args.fuse_chain_lanes
     B = args.batch
     # distinct synthetic images per rank (global batch = world * B), resident in HBM
     x_np = syn.synthetic_images(B, args.size, 100 + rank)
@@ -850,11 +809,10 @@ def run_regressor(args, rank, world, local_rank):
                    'global_batch': world * B, 'parallelism': f'dp{world}',
                    'multi_stream': not args.single_stream, 'conv_algo': algo,
                    'd2h_betas_in_timed_region': True,
-                   'fuse_add': int(net.backbone.fuse_add),
-                   'hip_graph': ('explicit' if net.backbone.use_graph == 'explicit' else
-                                 bool(net.backbone.use_graph is True or
-                                      (net.backbone.use_graph == 'auto' and
-                                       B <= net.backbone.graph_max_batch)))},
+                   'wino4_ksplit': {f'{c}@{t}': sl for (c, t), sl in net.backbone.wino4_ksplit.items()},
+                   'hip_graph': bool(net.backbone.use_graph is True or
+                                     (net.backbone.use_graph == 'auto' and
+                                      B <= net.backbone.graph_max_batch))},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak,
                      'unit': 'TFLOP/s', 'frac': achieved / peak,
                      'traffic': traffic['bytes_fetch_x2_corrected'] if traffic else None,
@@ -887,25 +845,14 @@ def run_regressor(args, rank, world, local_rank):
                                        'ONE GPU (work / side: through c10d, with its RCCL stream)'}
     import hashlib
     res['betas_sha1'] = hashlib.sha1(betas_host.numpy().tobytes()).hexdigest()[:16]
-    if getattr(args, 'check_vs_default', False):
-        # (after the timed region) the same batch through the DEFAULT plan of the same network: the
-        # in-process knobs off (fuse_add, the forced 64-channel tile); executor modes set through the
-        # environment stay as they are -- those must be bit-identical to the headline anyway
-        bb = net.backbone
-        keep = bb.fuse_add, bb.wino4_n64_cout
-        try:
-            bb.fuse_add, bb.wino4_n64_cout = 0, ()
-            with torch.no_grad():
-                ref = net(x, None)
-            res['check_vs_default'] = {
-                'reference': 'the default-plan forward of the same network and batch in the same process',
-                'features_maxabs': float((out['features'] - ref['features']).abs().max()),
-                'betas_maxabs': float((out['stage_02']['betas'] - ref['stage_02']['betas']).abs().max())}
-        finally:
-            bb.fuse_add, bb.wino4_n64_cout = keep
     if world == 1 and not getattr(args, 'no_also', False) and not getattr(args, '_sub', False):
         res['also'] = also_records(args, net, x)
-        res['also'].update(experimental_records(args, res.get('betas_sha1')))
+        # the same values as flat scalars (a line parser that keeps only top-level scalars keeps these)
+        for tag, rec in res['also'].items():
+            if isinstance(rec, dict) and 'value' in rec:
+                res[f'also_{tag}_value'] = rec['value']
+                res[f'also_{tag}_ms'] = rec['ms_per_step']
+                res[f'also_{tag}_roofline_frac'] = rec['roofline']['frac']
 
     def finish(res):                                 # rank 0 only; after destroy_process_group()
         if not args.no_cpu_baseline:
@@ -933,10 +880,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true',
                     help='skip the CPU oracle (cpu_baseline and parity fields)')
     ap.add_argument('--single-stream', action='store_true')
-    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off', 'explicit'],
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                     help='replay the backbone as one hipGraph (auto: never since round 3 -- the eager '
-                         'event-driven forward is faster at every batch size; on: the captured barrier plan; '
-                         'explicit: the event-driven plan as a hand-built graph)')
+                         'event-driven forward is faster at every batch size; on: the captured barrier plan)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f32x6', 'bf16'],
                     help='f32 = BASELINE configs[1] (headline) on the f32 matrix-core path; '
                          'f32x6 = same float32 tensors, products from the exact 3-way bf16 split '
@@ -945,7 +891,7 @@ def main():
                     help='f32 conv algorithm override (default: the backbone\'s own default)')
     ap.add_argument('--tile-flags', default='',
                     help='A/B knob bits OR-ed into every conv\'s tile id (shapy_amd/_lib.py), e.g. '
-                         '0x200000 = F(4x4) kernel with the 12-chunk loop unrolled')
+                         '0x10000 = m-major XCD order for large weights')
     ap.add_argument('--cpu-stub', action='store_true',
                     help='TEST HARNESS, never a measurement: gloo ranks + a stub CPU forward, to run the '
                          'N-rank control flow of this file without GPUs (tests/test_host_cpu.py); '
@@ -957,23 +903,15 @@ def main():
                     help='N = 1 only: create a world-size-1 RCCL group and take BetasGatherer\'s '
                          'collective path (rehearsal of the N-rank step on one GPU; the line says '
                          '"rccl_ranks": 1)')
-    ap.add_argument('--gather-mode', default=None, choices=['rccl', 'work', 'side'],
-                    help='BetasGatherer issue mode (shapy_amd/parallel.py; default: rccl = ncclAllGather '
-                         'called directly on the compute stream)')
+    ap.add_argument('--gather-mode', default=None, choices=['lane', 'rccl', 'work', 'side'],
+                    help='BetasGatherer issue mode (shapy_amd/parallel.py; default: lane = ncclAllGather '
+                         'called directly on the executor\'s lane-1 stream, joined one step later)')
     ap.add_argument('--control-backend', default='gloo', choices=['gloo', 'nccl'],
                     help='torch.distributed backend of the control plane at N > 1 (barriers, timing '
                          'reduction, RCCL id exchange); the betas all-gather is RCCL either way')
     ap.add_argument('--group-branches', default=None, choices=['auto', 'on', 'off'],
                     help='persistent grouped F(4x4) launches per depth level of a module '
                          '(HighResolutionNet.group_branches)')
-    ap.add_argument('--fuse-add', default=None, choices=['on', 'off', '0', '1', '2'],
-                    help='upsample terms of the fuse layers as low-resolution convs + one add pass (1 = on); '
-                         '2: also the stride-2 terms accumulated apart from x_i, one short add per output '
-                         '(HighResolutionNet.fuse_add; default: the backbone\'s own, 0)')
-    ap.add_argument('--check-vs-default', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--fuse-chain-lanes', default=None,
-                    help='with --fuse-add 2: lane policy of the stride-2 chains per stage, e.g. '
-                         '"dest,dest,mixed" (HighResolutionNet.fuse_chain_lanes)')
     ap.add_argument('--no-also', action='store_true',
                     help='skip the `also` sub-records (the other BASELINE configurations, timed after '
                          'the headline\'s timed region in the default N = 1 run)')

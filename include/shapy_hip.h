@@ -99,12 +99,12 @@ typedef struct ShapyConv {
                          never Winograd, 0x4000 / 0x8000 Winograd tile groups, 0x20000 Winograd K
                          loop chunk by chunk, 0x40000 / 0x80000 three / one chunk(s) of loads in
                          flight.  Speed only: every setting computes the same convolution.
-                         (0x200000: F(4x4) kernel with its 12-chunk loop unrolled, Cin = 192;
-                         0x400000: F(4x4) on the 64-channel N tile when Cout % 64 == 0 too;
-                         bits 24..30: F(4x4) kernels, start delay of a CU's second workgroup in
-                         units of 128 clocks, SHAPY_TILE_W4_STAGGER(n).)
-                         One bit describes DATA instead: SHAPY_TILE_WINO4 (0x100000) says that
-                         wgt_wino holds F(4x4,3x3) filters (below).                             */
+                         Two fields describe DATA / arithmetic instead: SHAPY_TILE_WINO4 (0x100000)
+                         says that wgt_wino holds F(4x4,3x3) filters (below); SHAPY_TILE_W4_KSPLIT(S)
+                         (bits 21..22 = S - 1, S = 1..4) runs such a layer with its K loop cut into S
+                         slices on S workgroups per output tile (split_ws / split_cnt below; the S
+                         partial sums are added in slice order, so the result is deterministic but
+                         differs from S = 1 in the last bits).                                   */
   int32_t dtype;      /* storage type of in / wgt / res / out: SHAPY_DTYPE_F32 (f32 MFMA, exact
                          f32) or SHAPY_DTYPE_BF16 (bf16 MFMA, f32 accumulate; Cin % 8 == 0, and
                          Cin >= 32 with ups == 1 when Cin % 32 != 0: the flat-K kernel)          */
@@ -121,9 +121,15 @@ typedef struct ShapyConv {
                          csrc/conv_wino4.hip (4x fewer MFMAs than the direct sum).  Tensors
                          beyond 1 GiB (the kernel's 32-bit offset scheme) run the direct kernel
                          on `wgt` instead; SHAPY_EINVAL when the layer shape does not qualify.  */
+  void *split_ws;     /* SHAPY_TILE_W4_KSPLIT(S > 1) only (ABI 8): S * B * ceil(Hi/4) * ceil(Wi/4) * 16
+                         * Cout floats of scratch, 16-byte aligned, private to this call while it runs */
+  int32_t *split_cnt; /* ... and 2 * ceil(B * ceil(Hi/4) * ceil(Wi/4) / 16) * (Cout / 16) int32
+                         arrival counters that are ZERO when the call starts; the kernel leaves them
+                         zero (so the same counters serve the next call on the same stream, but must
+                         be zeroed again after a failed / aborted launch)                         */
 } ShapyConv;
 #define SHAPY_TILE_WINO4 0x100000
-#define SHAPY_TILE_W4_STAGGER(n) (((n) & 0x7f) << 24)
+#define SHAPY_TILE_W4_KSPLIT(s) ((((s) - 1) & 3) << 21)
 
 int shapy_conv2d(const ShapyConv *desc_host, void *stream);
 
@@ -142,15 +148,7 @@ int shapy_conv2d_group(const ShapyConv *descs_host, int n, void *stream);
  * HRNet op list.  The host (Python) flattens the module tree into `ops`; buffers are
  * offsets (in floats, per image) into one workspace allocation that is scaled by B.
  * ------------------------------------------------------------------------------------- */
-enum { SHAPY_OP_CONV = 0, SHAPY_OP_STEM = 1, SHAPY_OP_MEANPOOL = 2, SHAPY_OP_FUSEADD = 3 };
-/* SHAPY_OP_FUSEADD (ABI 7): out[Ho, Wo, Cout] = [relu](res [+ extra] [+ up2(y1) [+ up4(y2) [+ up8(y3)]]])
-   -- the terms of one fuse output of a HighResolutionModule (reference hrnet.py:181-191) added in ONE pass
-   over the output, in this order.  res_off / res_ld / res_coff: the base tensor (may be the output itself);
-   wino_off: per-image WORKSPACE offset of a second full-resolution term (dense [Ho, Wo, Cout]; -1: none);
-   ksize = number of nearest-upsampled terms (0..3); in_off, wgt_off, bias_off = WORKSPACE offsets of y1,
-   y2, y3 (dense [Ho >> t, Wo >> t, Cout], t = 1, 2, 3), each produced by an ordinary 1x1 CONV op at its
-   own resolution.  Cout, the leading dimensions and channel offsets must be multiples of 16 bytes. */
-
+enum { SHAPY_OP_CONV = 0, SHAPY_OP_STEM = 1, SHAPY_OP_MEANPOOL = 2 };
 typedef struct ShapyOp {
   int32_t type;
   int32_t lane;                /* stream id (0..6; 0 = the caller's stream): ops of different
@@ -175,14 +173,32 @@ typedef struct ShapyOp {
   int64_t wgt_off, bias_off;            /* float offsets into the weight blob; -1 = none     */
   int64_t wino_off;                     /* float offset of the Winograd-transformed filters
                                            (ShapyConv.wgt_wino) in the blob; -1 = none        */
+  int64_t split_off;                    /* split-K layers (SHAPY_TILE_W4_KSPLIT in `tile`, ABI 8):
+                                           per-image float offset of ShapyConv.split_ws in the
+                                           workspace (S * ceil(Hi/4) * ceil(Wi/4) * 16 * Cout
+                                           floats per image); -1 = none                        */
+  int64_t cnt_off;                      /* ... and per-image int32 offset of ShapyConv.split_cnt
+                                           in the `counters` argument (2 * ceil(ceil(Hi/4) *
+                                           ceil(Wi/4) / 16) * (Cout / 16) per image); -1 = none */
 } ShapyOp;
 
 /* input: [B,3,H,W] NCHW f32 (the reference's layout, iterative_regressor.py:623);
- * features_out: [B, Cfeat].  workspace must hold B * ws_floats_per_image floats. */
+ * features_out: [B, Cfeat].  workspace must hold B * ws_floats_per_image floats.
+ * counters (ABI 8): B * cnt_per_image int32 for the split-K layers of the plan (ShapyOp.cnt_off), or
+ * NULL when cnt_per_image == 0.  The caller zeroes them ONCE after allocating them; every completed
+ * forward leaves them zero.  Like the workspace they belong to one forward at a time. */
 int shapy_hrnet_run(const ShapyOp *ops_host, int n_ops, const void *weights,
                     const float *input_nchw, void *workspace, int64_t ws_elems_per_image,
-                    float *features_out, int B, int H, int W, int multi_stream, int dtype,
-                    void *stream);
+                    int32_t *counters, int64_t cnt_per_image, float *features_out, int B, int H,
+                    int W, int multi_stream, int dtype, void *stream);
+
+/* The executor's side stream of `lane` (1..6; lanes 1..3 carry the branches of a HighResolutionModule)
+ * on the current device, created on first use and owned by the library.  For host-side work that should
+ * ride on a stream the process already has -- the RCCL all-gather of the predicted betas in a
+ * data-parallel step (shapy_amd/parallel.py, mode 'lane') -- instead of adding another one.  Work put
+ * there is ordered with the lane's ops of later forwards like any stream work; the caller orders it
+ * against its own stream with events. */
+int shapy_hrnet_lane_stream(int lane, void **stream_out);
 
 /* The same forward captured once into a hipGraph (side-stream branches included) and replayed
  * with one launch: removes the ~330 kernel launches + fork/join events per forward from the
@@ -192,16 +208,9 @@ int shapy_hrnet_run(const ShapyOp *ops_host, int n_ops, const void *weights,
  * reads `features_out` after it (stream-ordered).  ops_host is only read during create. */
 int shapy_hrnet_graph_create(const ShapyOp *ops_host, int n_ops, const void *weights,
                              const float *input_nchw, void *workspace,
-                             int64_t ws_elems_per_image, float *features_out, int B, int H,
-                             int W, int multi_stream, int dtype, void **graph_out);
-/* The op list's EVENT-DRIVEN form (sig / wait, lanes, barriers) as an explicitly built hipGraph:
- * kernel nodes read back from a single-stream capture, edges = the executor's ordering rules.  No
- * multi-stream capture is involved (which crashes in graph creation on ROCm 7.2 for this plan).
- * Launch / destroy with shapy_hrnet_graph_launch / _destroy. */
-int shapy_hrnet_graph_create_explicit(const ShapyOp *ops_host, int n_ops, const void *weights,
-                                      const float *input_nchw, void *workspace,
-                                      int64_t ws_elems_per_image, float *features_out, int B, int H,
-                                      int W, int dtype, void **graph_out);
+                             int64_t ws_elems_per_image, int32_t *counters, int64_t cnt_per_image,
+                             float *features_out, int B, int H, int W, int multi_stream, int dtype,
+                             void **graph_out);
 int shapy_hrnet_graph_launch(void *graph, void *stream);
 int shapy_hrnet_graph_destroy(void *graph);
 /* dtype = SHAPY_DTYPE_F32: weights / workspace are float32 (the parity path);

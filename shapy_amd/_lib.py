@@ -30,7 +30,7 @@ class ShapyConv(ctypes.Structure):
                 ('ksize', i32), ('stride', i32), ('pad', i32),
                 ('out_ld', i32), ('out_coff', i32), ('res_ld', i32), ('res_coff', i32),
                 ('relu', i32), ('ups', i32), ('tile', i32), ('dtype', i32),
-                ('reserved0', i32), ('wgt_wino', vp)]
+                ('reserved0', i32), ('wgt_wino', vp), ('split_ws', vp), ('split_cnt', vp)]
 
 
 class ShapyOp(ctypes.Structure):
@@ -41,7 +41,8 @@ class ShapyOp(ctypes.Structure):
                 ('relu', i32), ('ups', i32), ('tile', i32), ('group', i32),
                 ('sig', i32), ('wait', i32 * 3),
                 ('in_off', i64), ('out_off', i64), ('res_off', i64),
-                ('wgt_off', i64), ('bias_off', i64), ('wino_off', i64)]
+                ('wgt_off', i64), ('bias_off', i64), ('wino_off', i64),
+                ('split_off', i64), ('cnt_off', i64)]
 
 
 class ShapySmplxModel(ctypes.Structure):
@@ -53,7 +54,7 @@ class ShapySmplxModel(ctypes.Structure):
                 ('dyn_lmk_bary', vp), ('neck_kin_chain', vp)]
 
 
-OP_CONV, OP_STEM, OP_MEANPOOL, OP_FUSEADD = 0, 1, 2, 3
+OP_CONV, OP_STEM, OP_MEANPOOL = 0, 1, 2
 POSE_ROTMAT, POSE_CONT6D, POSE_AXIS_ANGLE = 0, 1, 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F32X6 = 0, 1, 2
 TILES = {'auto': 0, '256x48': 1, '128x96': 2, '128x128': 3, '256x64': 4, '64x48': 5,
@@ -71,13 +72,21 @@ for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: con
     TILES[_k + '+pd1'] = _v | 0x80000         # ... 1 chunk (float32 default)
     TILES[_k + '+noallk'] = _v | 0x20000      # Winograd: K loop chunk by chunk even for Cin = 48 / 64
 TILE_WINO4 = 0x100000                   # ShapyConv.wgt_wino holds F(4x4,3x3) filters (conv_wino4.hip)
-TILE_WINO4_N64 = 0x400000               # A/B knob: F(4x4) on the 64-channel N tile when Cout % 64 == 0 too (192, 384)
-TILE_WINO4_UNROLL12 = 0x200000          # A/B knob: F(4x4) kernel with its 12-chunk loop unrolled (Cin = 192)
 
 
-def tile_w4_stagger(n):
-    """F(4x4) kernels: start delay of a CU's second workgroup, n units of 128 clocks (bits 24..30)."""
-    return (int(n) & 0x7f) << 24
+def tile_w4_ksplit(s):
+    """SHAPY_TILE_W4_KSPLIT(s): an F(4x4) layer with its K loop cut into s = 1..4 slices (bits 21..22)."""
+    if not 1 <= int(s) <= 4:
+        raise ValueError(f'F(4x4) split-K: 1..4 slices, got {s}')
+    return (int(s) - 1) << 21
+
+
+def w4_split_sizes(H, W, cout, s):
+    """(slab floats per image, counter ints per image) of an F(4x4) split-K layer on an H x W map
+    (include/shapy_hip.h: ShapyConv.split_ws / split_cnt)."""
+    t = ((H + 3) // 4) * ((W + 3) // 4)
+    return s * t * 16 * cout, 2 * ((t + 15) // 16) * (cout // 16)
+
 
 #: every symbol include/shapy_hip.h declares: (restype, argtypes)
 SIGNATURES = {
@@ -85,16 +94,14 @@ SIGNATURES = {
     'shapy_build_arch': (ctypes.c_char_p, []),
     'shapy_conv2d': (ctypes.c_int, [ctypes.POINTER(ShapyConv), vp]),
     'shapy_conv2d_group': (ctypes.c_int, [ctypes.POINTER(ShapyConv), ctypes.c_int, vp]),
-    'shapy_hrnet_run': (ctypes.c_int, [ctypes.POINTER(ShapyOp), ctypes.c_int, vp, vp, vp, i64, vp,
+    'shapy_hrnet_run': (ctypes.c_int, [ctypes.POINTER(ShapyOp), ctypes.c_int, vp, vp, vp, i64, vp, i64, vp,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, vp]),
     'shapy_hrnet_graph_create': (ctypes.c_int, [ctypes.POINTER(ShapyOp), ctypes.c_int, vp, vp, vp, i64,
-                                                vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                vp, i64, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_void_p)]),
-    'shapy_hrnet_graph_create_explicit': (ctypes.c_int, [ctypes.POINTER(ShapyOp), ctypes.c_int, vp, vp, vp,
-                                                         ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int,
-                                                         ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]),
+    'shapy_hrnet_lane_stream': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp)]),
     'shapy_hrnet_graph_launch': (ctypes.c_int, [vp, vp]),
     'shapy_hrnet_graph_destroy': (ctypes.c_int, [vp]),
     'shapy_regressor_affine_f32': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int,

@@ -46,10 +46,10 @@ struct ConvK {
   int no_allk;                  // tuning: Winograd K loop always chunk by chunk
   int flat;                     // bf16, Cin % 32 != 0: flat-K kernel
   int pd3;                      // implicit GEMM: three chunks of global loads in flight
-  int dbg;                      // -DSHAPY_WINO_TIMING builds only: ablation mask (wrong results)
-  int w4_unroll12;              // tuning: F(4x4) kernel with the 12-chunk loop unrolled (Cin = 192)
-  int w4_n64;                   // tile flag 0x400000: F(4x4) on the 64-channel N tile when Cout % 64 == 0
-  int w4_stagger;               // F(4x4): start delay of a CU's second workgroup, units of 128 clocks
+  int ksplit;                   // F(4x4): K slices per output tile (SHAPY_TILE_W4_KSPLIT), 1 = none
+  void *split_ws;               // ... their slab (ShapyConv.split_ws) and its size (conv2d_wino4)
+  unsigned split_bytes;
+  int *split_cnt;               // ... and arrival counters (ShapyConv.split_cnt; zero between launches)
 };
 
 // Winograd F(2x2,3x3) path of the float32 3x3 / stride-1 layers (conv_wino.hip)

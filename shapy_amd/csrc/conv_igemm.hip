@@ -357,10 +357,10 @@ int conv_prepare(const ShapyConv &d, ConvK &k, int *empty) {
   k.swz = (d.tile & 0x400) ? 0 : 1;
   k.no_nslab = (d.tile & 0x10000) ? 1 : 0;
   k.no_allk = (d.tile & 0x20000) ? 1 : 0;
-  k.dbg = 0;
-  k.w4_unroll12 = 0;
-  k.w4_n64 = 0;
-  k.w4_stagger = (d.tile >> 24) & 0x7f;       // F(4x4) kernels: SHAPY_TILE_W4_STAGGER(n)
+  // F(4x4) split-K (conv_wino4.hip): SHAPY_TILE_W4_KSPLIT(S) in the tile word, slab + counters from
+  // the caller
+  k.ksplit = ((d.tile >> 21) & 3) + 1;
+  k.split_ws = d.split_ws; k.split_bytes = 0; k.split_cnt = d.split_cnt;
   k.flat = flat ? 1 : 0;
   return SHAPY_OK;
 }
@@ -380,8 +380,6 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
   // the host's policy again: HighResolutionNet.conv_algo = 'winograd4') -- there is no other
   // kernel for that layout, so an ineligible layer is an error, not a fallback
   if (d.tile & 0x100000) {
-    k.w4_unroll12 = (d.tile & 0x200000) ? 1 : 0;
-    k.w4_n64 = (d.tile & 0x400000) ? 1 : 0;
     if (conv_wino4_fits(k)) {      // (size limits first: conv_wino_eligible also refuses > 2 GiB)
       if (d.dtype != SHAPY_DTYPE_F32 || !conv_wino_eligible(k)) return SHAPY_EINVAL;
       return conv2d_wino4(k, s);
@@ -439,7 +437,9 @@ int conv2d_group(const ShapyConv *ds, int n, hipStream_t s) {
   int m = 0;
   for (int i = 0; i < n; ++i) {
     const ShapyConv &d = ds[i];
-    if (d.dtype != SHAPY_DTYPE_F32 || !(d.tile & 0x100000) || !d.wgt_wino) return SHAPY_EINVAL;
+    // (the persistent kernel has no split-K form: such layers go one by one)
+    if (d.dtype != SHAPY_DTYPE_F32 || !(d.tile & 0x100000) || !d.wgt_wino || ((d.tile >> 21) & 3))
+      return SHAPY_EINVAL;
     int empty = 0;
     const int rc = conv_prepare(d, ks[m], &empty);
     if (rc != SHAPY_OK) return rc;

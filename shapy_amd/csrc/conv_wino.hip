@@ -41,22 +41,6 @@ __device__ __forceinline__ float quad_partner(float x) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x5A, 0xf, 0xf, true));
 }
 
-// Phase timing of one workgroup (tuning builds only: -DSHAPY_WINO_TIMING, read back with
-// shapy_debug_wino_times; wall_clock64 ticks at 100 MHz)
-#ifdef SHAPY_WINO_TIMING
-__device__ unsigned long long g_wino_times[16];
-#define WINO_STAMP(slot)                                                            \
-  do {                                                                              \
-    if (blockIdx.x == gridDim.x / 2 + 1 && threadIdx.x == 0) g_wino_times[slot] = wall_clock64(); \
-  } while (0)
-#define WINO_DBG(bit) (p.dbg & (bit))
-#else
-#define WINO_STAMP(slot) do {} while (0)
-#define WINO_DBG(bit) false
-#endif
-
-__device__ __forceinline__ bool v_dbg_skip(const f32x4 &v) { return v[0] != 12345.678f; }
-
 // KC > 0: the layer has exactly KC K chunks (Cin = 16 KC) and ALL of them are staged in the
 // prologue (KC V buffers, which fit into the memory the accumulator exchange needs anyway): the K
 // loop then runs without barriers and without waiting for patch rows.  The generic loop (KC = 0)
@@ -75,10 +59,9 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
   __shared__ __attribute__((aligned(16))) char lds[NVB * LDS_V > LDS_X ? NVB * LDS_V : LDS_X];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  WINO_STAMP(0);
   const int wg = conv_tile_index(p);
   const int m_blk = (wg / p.nbx) * MT, n_blk = (wg % p.nbx) * N;
-  const int m_ld = WINO_DBG(2) ? 0 : m_blk;           // ablation: every workgroup loads tile group 0
+  const int m_ld = m_blk;
   const int H = p.Hi, W = p.Wi;
   const int TW = (W + 1) >> 1, TH = (H + 1) >> 1;
   const int T = p.wino_tiles;
@@ -199,9 +182,7 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
 
   u32x4 bfr[4][NN];
   auto bload = [&](int pp, int cc, bool live) {
-    int base = live ? u_lane + (4 * wave + pp) * u_pos_stride + cc * u_chunk_stride : OOB - 4096;
-    if (WINO_DBG(1)) base = live ? u_lane : OOB - 4096;           // ablation: one hot 3 KB of filters
-    if (WINO_DBG(16) && cc > 0) return;                           // ablation: no filter refills at all
+    const int base = live ? u_lane + (4 * wave + pp) * u_pos_stride + cc * u_chunk_stride : OOB - 4096;
 #pragma unroll
     for (int n = 0; n < NN; ++n)
       bfr[pp][n] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, base + n * 1024, 0, 0);
@@ -235,10 +216,9 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
         for (int m = 0; m < TM; ++m)
 #pragma unroll
           for (int n = 0; n < NN; ++n)
-            if (!WINO_DBG(8) || kk == 0)
-              acc[pp][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                  __uint_as_float(af[pp & 1][m][kk]), __uint_as_float(bfr[pp][n][kk]),
-                  acc[pp][m][n], 0, 0, 0);
+            acc[pp][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                __uint_as_float(af[pp & 1][m][kk]), __uint_as_float(bfr[pp][n][kk]),
+                acc[pp][m][n], 0, 0, 0);
       // keep the refill of this position's B fragments HERE (hipcc otherwise sinks all 12 loads
       // to the end of the iteration, one LDS store + barrier before their first use)
       __builtin_amdgcn_sched_barrier(0);
@@ -263,11 +243,9 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
     for (int c = 0; c < KC; ++c) lstore(c, rawk[c]);
     gload(0, false);                         // residual pixels: land during the K loop
     __syncthreads();
-    WINO_STAMP(1);
 #pragma unroll
     for (int cc = 0; cc < KC; ++cc) {
       multiply(lds + cc * LDS_V, cc, cc + 1 < KC);
-      if (cc == 0) WINO_STAMP(2);
     }
     __syncthreads();                         // every wave is done with V: the exchange may overwrite it
   } else {
@@ -276,7 +254,6 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
     for (int pp = 0; pp < 4; ++pp) bload(pp, 0, true);
     lstore(0, raw);
     __syncthreads();
-    WINO_STAMP(1);
 
     for (int cc = 0; cc < CC; ++cc) {
       const bool more = cc + 1 < CC;
@@ -286,10 +263,8 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
       // barrier below: it can be overwritten while slower waves still multiply this one
       if (more) lstore((cc + 1) & 1, raw);     // (after the last chunk raw[] holds the residual)
       __syncthreads();
-      if (cc == 0) WINO_STAMP(2);
     }
   }
-  WINO_STAMP(3);
 
   float *out = reinterpret_cast<float *>(p.out);
   static_assert(16 * N4 <= 256, "one (tile, 4 channels) epilogue item per thread");
@@ -325,7 +300,6 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
             M[((4 * wave + pp) * 16 + 4 * kq + rg) * NCP + n * 16 + l15] = acc[pp][mt][n][rg];
     }
     __syncthreads();
-    if (mt == 0) WINO_STAMP(4);
 
     // ---- output transform + bias + residual + ReLU + store ----
     if (active) {
@@ -350,7 +324,7 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-          if (!ok[a][bb] || (WINO_DBG(4) && v_dbg_skip(y[a][bb]))) continue;
+          if (!ok[a][bb]) continue;
           f32x4 v = y[a][bb] + rv[a][bb];
           if (p.relu) {
 #pragma unroll
@@ -360,7 +334,6 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
         }
     }
   }
-  WINO_STAMP(5);
 }
 
 bool conv_wino_eligible(const ConvK &k) {
@@ -391,9 +364,6 @@ int conv2d_wino(ConvK k, int tm, hipStream_t s) {
   if (tm == 0) tm = (k.Cin >= 192 && (long)((k.wino_tiles + 31) / 32) * k.nbx >= 384) ? 2 : 1;
   if (nn == 4) tm = 1;                                 // 64 accumulator + 64 B-fragment registers
   k.nby = (k.wino_tiles + 16 * tm - 1) / (16 * tm);
-#ifdef SHAPY_WINO_TIMING
-  k.dbg = getenv("SHAPY_WINO_DBG") ? atoi(getenv("SHAPY_WINO_DBG")) : 0;
-#endif
   // transformed filters larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
   if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt2_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
   // all-K staging (no barriers / patch waits inside the K loop) where the whole K extent fits the
@@ -415,9 +385,3 @@ int conv2d_wino(ConvK k, int tm, hipStream_t s) {
 }
 
 }  // namespace shapy
-
-#ifdef SHAPY_WINO_TIMING
-extern "C" int shapy_debug_wino_times(unsigned long long *out_host) {
-  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(shapy::g_wino_times), sizeof(unsigned long long) * 16);
-}
-#endif

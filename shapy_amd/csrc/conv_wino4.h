@@ -55,22 +55,6 @@ __device__ __forceinline__ void wino4_at4(const f32x4 (&m)[6], f32x4 (&o)[4]) {
   }
 }
 
-// Start stagger of the multiplying waves (both F(4x4) kernels).  Two workgroups share a CU and every
-// SIMD's matrix core is shared by one multiplying wave of each; launched together, both multiply at
-// the same time (each at half rate) and then both sit in their epilogue / wait for the next staged
-// chunk with the matrix cores idle.  An offset d between their multiply phases is PRESERVED from task
-// to task (whoever multiplies alone runs at full rate, so the phases neither converge nor drift), so
-// one delay at the start -- d ~ epilogue + hand-over time -- puts one workgroup's memory phase under
-// the other's MFMA phase for the whole launch.  The second workgroup of a CU is the one whose waves
-// got wave slot 1 of their SIMD (HW_ID[0]; speed only: a wrong guess costs nothing but the delay).
-__device__ __forceinline__ void wino4_start_stagger(int units) {
-  if (units <= 0) return;
-  unsigned hw_id;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-  if (hw_id & 1u)
-    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(2);       // 2 x 64 clocks
-}
-
 // Epilogue of a multiplying wave (both F(4x4) kernels).  The MFMAs run with the FILTER fragment as
 // the A operand and the V fragment as B, so the C layout is D[channel 4 g + r][tile l15]: a lane
 // holds ONE tile and FOUR CONSECUTIVE output channels of it in every accumulator -- the output
@@ -86,7 +70,6 @@ __device__ __forceinline__ void wino4_start_stagger(int units) {
 // image (partial edge tiles) and dead tiles get an out-of-range offset, which drops the access.
 // The residual of one pixel column (4 pixels) is in flight ahead of the one being transformed.
 struct Wino4Epi {
-  int dbg;                     // tuning builds (-DSHAPY_W4G_TIMING): 1 no stores, 2 no residual loads
   void *out;
   const void *res;             // nullptr: none
   const void *in;              // any valid address for the residual resource when res is null
@@ -94,12 +77,83 @@ struct Wino4Epi {
   int H, W, tiles, out_ld, out_coff, res_ld, res_coff, relu;
 };
 
-// tile: the lane's tile (m_blk + l15); col4: its first output channel (n0 + 4 g4)
-__device__ __forceinline__ void wino4_epilogue(const Wino4Epi &e, const f32x4 (&acc)[36], int tile,
-                                               int col4) {
+// Split-K (conv_wino4.hip, template parameter S > 1): the K loop of one (16 tiles x N channels) output
+// tile is cut into S slices that run as S workgroups; every multiplying WAVE is its own reduction unit
+// (its 16 tiles x 16 channels), so no workgroup barrier is involved.  Protocol per wave unit, following
+// the in-launch split-K recipe of the CDNA programming guide (section 6, guideline 16):
+//   * at the start of its LAST chunk a wave draws a ticket (relaxed agent-scope fetch_add; the latency
+//     hides behind the chunk's 144 MFMAs).  Tickets 0 .. S-2: output transform, the 16 pixels x 4
+//     channels of the lane go to the slice's slab as 16-byte WRITE-THROUGH stores (sc1), the wave drains
+//     its stores (s_waitcnt vmcnt(0)) and adds 1 to the unit's `done` counter.  Ticket S-1 = the reducer:
+//     polls `done` relaxed until it reads S-1 -- every other slice already holds a ticket, i.e. is
+//     resident and past its last barrier, so the wait is bounded --, reads the other slabs with sc1
+//     loads, adds the S partial outputs IN SLICE ORDER (own partial from registers: the sum does not
+//     depend on who arrived last), then bias + residual + ReLU + store as without a split, and puts both
+//     counters back to 0 for the next launch that uses them.
+//   * the output transform is linear, so the slices exchange TRANSFORMED partials: 16 values per
+//     (tile, channel) instead of 36.
+// Slab layout [slice][n tile x wave][pixel 4 bb + a][tile][16 channels] f32: for a fixed pixel the 64
+// lanes of a wave (16 tiles x 4 channel quads) write one contiguous 1 KB run.  Counters: two ints per
+// (m tile, n tile, wave), zero before the first launch (the caller's job, include/shapy_hip.h).
+struct Wino4Split {
+  void *slab;
+  unsigned slab_bytes;
+  int slice;                   // this workgroup's K slice
+  int unit;                    // (n tile * waves + wave): slab index inside a slice
+  int n_units;                 // n tiles * waves
+  int *cnt;                    // this wave unit's {ticket, done}
+};
+
+// tile: the lane's tile (m_blk + l15); col4: its first output channel (n0 + 4 g4); g4 = lane >> 4.
+// S == 1: no split (sp / ticket unused).
+template <int S>
+__device__ __forceinline__ void wino4_epilogue(const Wino4Epi &e, const Wino4Split &sp, int ticket,
+                                               const f32x4 (&acc)[36], int tile, int col4, int g4,
+                                               int lane) {
   constexpr int BAD = 0x40000000;
   const int H = e.H, W = e.W;
   const int TW = (W + 3) >> 2, TH = (H + 3) >> 2;
+  const bool live = tile < e.tiles;
+  f32x4 s[6][4];
+  auto transform_x = [&]() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const f32x4 m[6] = {acc[6 * i + 0], acc[6 * i + 1], acc[6 * i + 2],
+                          acc[6 * i + 3], acc[6 * i + 4], acc[6 * i + 5]};
+      wino4_at4(m, s[i]);                                         // M A   (along x)
+    }
+  };
+  // slab addressing: per-lane part = the tile + channel quad, slice / unit / pixel = scalar offset
+  const __amdgpu_buffer_rsrc_t rs_slab =
+      __builtin_amdgcn_make_buffer_rsrc(S > 1 ? sp.slab : e.out, 0, S > 1 ? sp.slab_bytes : 0, 0x00020000);
+  const int slab_lane = live ? (tile * 16 + 4 * g4) * 4 : BAD;
+  const int px_bytes = e.tiles * 64, unit_bytes = 16 * px_bytes;
+  if constexpr (S > 1) {
+    if (ticket != S - 1) {
+      // ---- not the last slice of this unit to arrive: publish the transformed partial and leave ----
+      transform_x();
+      const int base = (sp.slice * sp.n_units + sp.unit) * unit_bytes;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const f32x4 colv[6] = {s[0][bb], s[1][bb], s[2][bb], s[3][bb], s[4][bb], s[5][bb]};
+        f32x4 y[4];
+        wino4_at4(colv, y);                                       // A^T (M A)   (along y)
+        // (the 16-byte store hazard of the output stores below applies here too: four finished register
+        // quads, no vector instruction between or right behind the stores)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[a]), rs_slab, slab_lane,
+                                                 base + (4 * bb + a) * px_bytes, /*sc1*/ 16);
+        asm volatile("s_nop 1");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // every storing wave drains its own write-through stores, then one lane reports
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) (void)__hip_atomic_fetch_add(sp.cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
   f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
   if (e.bias) bias = f32x4{e.bias[col4], e.bias[col4 + 1], e.bias[col4 + 2], e.bias[col4 + 3]};
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, BAD, 0x00020000);
@@ -107,7 +161,6 @@ __device__ __forceinline__ void wino4_epilogue(const Wino4Epi &e, const f32x4 (&
       const_cast<void *>(e.res ? e.res : e.in), 0, BAD, 0x00020000);
   const bool has_res = e.res != nullptr;
   const int out_ld = e.out_ld, res_ld = e.res_ld;
-  const bool live = tile < e.tiles;
   const int tt = live ? tile : 0;
   const int tx = tt % TW;
   const int tq = tt / TW;
@@ -123,36 +176,74 @@ __device__ __forceinline__ void wino4_epilogue(const Wino4Epi &e, const f32x4 (&
   auto rload = [&](int bb, f32x4 (&rv)[4]) {       // pixel column bb of the tile: 4 pixels
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      bool ok = (a < nrow) & (bb < ncol);
-#if defined(SHAPY_W4G_TIMING) || defined(SHAPY_WINO_TIMING)
-      ok &= !(e.dbg & 2);
-#endif
+      const bool ok = (a < nrow) & (bb < ncol);
       rv[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                             rs_res, ok ? rbase : BAD, (a * W + bb) * res_ld * 4, 0));
     }
   };
-  rload(0, resv[0]);
-  f32x4 s[6][4];
+  // reducer: column bb of the S - 1 OTHER slices' partials, in slice order (all loads unconditional:
+  // a "register or load" choice per element would make hipcc branch around every load)
+  constexpr int SO = S > 1 ? S - 1 : 1;
+  f32x4 part[2][SO][4];
+  auto pload = [&](int bb, f32x4 (&pv)[SO][4]) {
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const f32x4 m[6] = {acc[6 * i + 0], acc[6 * i + 1], acc[6 * i + 2],
-                        acc[6 * i + 3], acc[6 * i + 4], acc[6 * i + 5]};
-    wino4_at4(m, s[i]);                                           // M A   (along x)
+    for (int k = 0; k < SO; ++k) {
+      const int other = k + (k >= sp.slice ? 1 : 0);
+      const int base = (other * sp.n_units + sp.unit) * unit_bytes;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        pv[k][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 rs_slab, slab_lane, base + (4 * bb + a) * px_bytes, /*sc1*/ 16));
+    }
+  };
+  rload(0, resv[0]);
+  transform_x();
+  if constexpr (S > 1) {
+    // the other slices' partials are complete when `done` reads S - 1 (each adds 1 behind its drained
+    // write-through stores); relaxed polling by one lane, the sc1 loads below bypass this CU's L1
+    if (lane == 0)
+      while (__hip_atomic_load(sp.cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S - 1)
+        __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    pload(0, part[0]);
   }
 #pragma unroll
   for (int bb = 0; bb < 4; ++bb) {
-    if (bb + 1 < 4) rload(bb + 1, resv[(bb + 1) & 1]);
+    if (bb + 1 < 4) {
+      rload(bb + 1, resv[(bb + 1) & 1]);
+      if constexpr (S > 1) pload(bb + 1, part[(bb + 1) & 1]);
+    }
     const f32x4 colv[6] = {s[0][bb], s[1][bb], s[2][bb], s[3][bb], s[4][bb], s[5][bb]};
     f32x4 y[4];
     wino4_at4(colv, y);                                           // A^T (M A)   (along y)
+    if constexpr (S == 2) {
+      // (two terms: the sum is the same whichever of them is the register)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) y[a] = y[a] + part[bb & 1][0][a];
+    } else if constexpr (S > 2) {
+      // slice order 0 .. S-1, the own partial at position sp.slice (selects on loaded registers only)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        f32x4 sum;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          const f32x4 below = part[bb & 1][j < SO ? j : SO - 1][a];       // slice j when j < sp.slice
+          const f32x4 above = part[bb & 1][j > 0 ? j - 1 : 0][a];         // slice j when j > sp.slice
+          const f32x4 t = j == sp.slice ? y[a] : (j < sp.slice ? below : above);
+          sum = j == 0 ? t : sum + t;
+        }
+        y[a] = sum;
+      }
+    }
     f32x4 v[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       v[a] = (y[a] + bias) + resv[bb & 1][a];
-      // ReLU without a branch per store and without hipcc's canonicalising second v_max:
-      // max(v, 0) or max(v, -inf)
+      // ReLU without a branch per store: clamp from below at 0 or at -inf.  Compare + select, not v_max:
+      // v_max_f32 returns the OTHER operand for a NaN input, which would turn a NaN activation into 0
+      // (or -inf) and hide a numerical blow-up from the Winograd guard; NaN < lo is false, so it passes.
 #pragma unroll
-      for (int k = 0; k < 4; ++k) asm("v_max_f32 %0, %1, %2" : "=v"(v[a][k]) : "v"(v[a][k]), "v"(relu_lo));
+      for (int k = 0; k < 4; ++k) v[a][k] = v[a][k] < relu_lo ? relu_lo : v[a][k];
     }
     // The four pixels of the column are complete (four DIFFERENT register quads) before the first
     // store is issued, and nothing may write a VGPR for two wait states after the last one:
@@ -163,10 +254,7 @@ __device__ __forceinline__ void wino4_epilogue(const Wino4Epi &e, const f32x4 (&
     int voff[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      bool ok = (a < nrow) & (bb < ncol);
-#if defined(SHAPY_W4G_TIMING) || defined(SHAPY_WINO_TIMING)
-      if (e.dbg & 1) ok &= v[a][0] == 12345.678f;
-#endif
+      const bool ok = (a < nrow) & (bb < ncol);
       voff[a] = ok ? obase : BAD;
     }
     // (addresses included: no vector instruction at all between the four stores)
@@ -177,6 +265,14 @@ __device__ __forceinline__ void wino4_epilogue(const Wino4Epi &e, const f32x4 (&
                                              (a * W + bb) * out_ld * 4, 0);
     asm volatile("s_nop 1");
     __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (S > 1) {
+    // every other slice has left the counters (its `done` add was its last access): back to zero for
+    // the next launch on them
+    if (lane == 0) {
+      __hip_atomic_store(sp.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sp.cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

@@ -32,22 +32,10 @@
 //     cover the pixel's whole 192-byte row).
 // The fourth wave only stages: the register budget (256 per lane) allows two waves per SIMD either
 // way, so the slot costs no occupancy.
-#include <stdlib.h>
-
 #include "conv_common.h"
 #include "conv_wino4.h"
 
 namespace shapy {
-
-// Ablation switches of tuning builds (-DSHAPY_WINO_TIMING, ConvK.dbg from SHAPY_WINO_DBG; results are
-// WRONG on purpose): 1 no output stores, 2 no residual loads, 4 a quarter of the MFMAs, 8 no filter
-// refills after the first ring, 16 patch loaded once (first chunk's registers reused), 32 no input
-// transform / LDS stores in the staging wave
-#ifdef SHAPY_WINO_TIMING
-#define W4_DBG(bit) (p.dbg & (bit))
-#else
-#define W4_DBG(bit) false
-#endif
 
 // 256 threads = three multiplying waves (16 output channels each, N = 48 per workgroup) + one
 // staging wave.  KC > 0: the layer has exactly KC chunks (Cin = 16 KC) and the multiplying waves'
@@ -58,25 +46,13 @@ namespace shapy {
 // or 4 (N = 64, 320 threads: layers whose Cout is a multiple of 64 but not of 48 -- layer1's 64 -> 64
 // and the head's 512 -> 512; five waves of 256 registers leave room for ONE workgroup per CU, all four
 // SIMDs multiply and the staging wave shares one of them).
-#ifdef SHAPY_W4_TOKEN
-// A/B variant (never built into the product library; first GPU runs of round 5, tools/runs/r05_b.sh).
-// tools/prio_probe.hip showed that s_setprio does NOT arbitrate the matrix pipe between the two waves of a
-// SIMD (2,265 vs 2,297 us for the higher / lower priority, profiles/r04ab_prio_probe.txt), so the two
-// workgroups of a CU always share it, finish their multiply phases together and run their epilogues
-// together with the pipe idle.  Here the multiply phase of a short (<= SHAPY_W4_TOKEN
-// chunks) workgroup is bracketed by a per-CU token in global memory (both residents sit behind the same
-// XCD's L2, where the atomics execute): one workgroup multiplies at the full rate while the other runs its
-// epilogue / next prologue.  Timing only -- no data depends on the token -- hence relaxed atomics.
-__device__ int w4_token[16 * 256];
-__device__ __forceinline__ int *w4_token_slot() {
-  unsigned hw, xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  return w4_token + (xcc & 15u) * 256 + ((hw >> 8) & 255u);           // XCC | SE, SH, CU
-}
-#endif
-
-template <int KC, int NW = 3>
+// S > 1: split-K.  The layers with few output tiles and a deep K loop -- 384 -> 384 on the 7x7 maps: 128
+// workgroups of 24 chunks at B = 64, half the CUs idle and every conv of the branch a 60 us serial chain
+// (113 us under the contention of a stage-4 module, where this lane ends 300-400 us after the others:
+// profiles/r04o_module_tails.txt) -- run S workgroups per output tile, each over Cin / S input channels;
+// the wave units exchange their transformed partials through a slab and the last to arrive finishes
+// (conv_wino4.h: Wino4Split).  KC = chunks of ONE slice.
+template <int KC, int NW = 3, int S = 1>
 __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
   constexpr int N = 16 * NW;
   constexpr int PSTR = 1024;                          // bytes per position: 16 tiles x 16 ch f32
@@ -88,12 +64,17 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // wave-uniform: scalar branches
+  // workgroup -> (m tile, K slice, n tile): the S slices of an output tile are neighbours in the m-major
+  // order of conv_tile_index (same XCD, dispatched together)
   const int wg = conv_tile_index(p);
-  const int m_blk = (wg / p.nbx) * 16, n_blk = (wg % p.nbx) * N;
+  const int mv = wg / p.nbx, n_i = wg % p.nbx;
+  const int m_i = mv / S, slice = mv % S;
+  const int m_blk = m_i * 16, n_blk = n_i * N;
   const int H = p.Hi, W = p.Wi;
   const int TW = (W + 3) >> 2, TH = (H + 3) >> 2;
   const int T = p.wino_tiles;
-  const int CC = p.Cin >> 4;
+  const int CC = (p.Cin >> 4) / S;                    // chunks of this workgroup's slice ...
+  const int cbase = slice * CC;                       // ... which starts at chunk cbase of the layer
 
   if (wave == NW) {
     // =========================== staging wave ===========================
@@ -142,9 +123,8 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(row_off[i] + co), 0, 0));
     };
 #pragma unroll
-    for (int j = 0; j < 6; ++j) gload_col(j, 0);
+    for (int j = 0; j < 6; ++j) gload_col(j, cbase * 16);
     for (int cc = 0; cc < CC; ++cc) {
-      if (W4_DBG(32)) { wino4_lds_barrier(); continue; }
       // chunk cc -> V buffer cc & 1.  That buffer was last read by the multiply of chunk
       // cc - 2, which every wave left through the barrier this wave passed at the end of the
       // previous iteration.
@@ -183,7 +163,7 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
         // the column's registers are free again: request the same column of the NEXT chunk, which
         // then has a whole multiply phase to arrive
         __builtin_amdgcn_sched_barrier(0);
-        if (more && !W4_DBG(16)) gload_col(j, (cc + 1) * 16);
+        if (more) gload_col(j, (cbase + cc + 1) * 16);
         __builtin_amdgcn_sched_barrier(0);
       }
       wino4_lds_barrier();                   // chunk cc is staged (barrier #cc of CC + 1)
@@ -194,33 +174,13 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
 
   // =========================== multiplying waves ===========================
   // wave w owns output channels n_blk + 16 w .. + 15 for ALL 36 positions
-  wino4_start_stagger(p.w4_stagger);
-#ifdef SHAPY_W4_PRIO
-  __builtin_amdgcn_s_setprio(SHAPY_W4_PRIO);    // A/B: multiplying waves above the staging waves
-#endif
-#ifdef SHAPY_W4_PRIO_PARITY
-  // A/B: the two workgroups of a CU get DIFFERENT issue priorities for their multiply phases (wave slot
-  // id of the SIMD, low two bits), so that the matrix pipe serves one of them at full rate and that one
-  // reaches its epilogue while the other still multiplies, instead of both sharing the pipe and then
-  // both finishing at once (in-phase residents).  Back to 0 for the epilogue.
-  {
-    unsigned hw_id;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-    switch (hw_id & 3u) {
-      case 0: __builtin_amdgcn_s_setprio(3); break;
-      case 1: __builtin_amdgcn_s_setprio(2); break;
-      case 2: __builtin_amdgcn_s_setprio(1); break;
-      default: __builtin_amdgcn_s_setprio(0); break;
-    }
-  }
-#endif
   const __amdgpu_buffer_rsrc_t rs_u =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt2), 0, p.wgt2_bytes, 0x00020000);
   const int g = lane >> 4, l15 = lane & 15;
   const int frag_off = l15 * 64 + (((g ^ l15 ^ (l15 >> 1)) & 3) << 4);
   const int n0 = n_blk + 16 * wave;
   const int u_lane = ((n0 + l15) * 16 + 4 * g) * 4;
-  const int u_pos = CC * p.Cout * 64, u_chunk = p.Cout * 64;
+  const int u_pos = (p.Cin >> 4) * p.Cout * 64, u_chunk = p.Cout * 64;
 
   // B-fragment loads: the per-lane part of the address is ONE register (u_lane); position and
   // chunk go into the scalar offset of the buffer instruction (as a vector offset hipcc keeps 36
@@ -228,7 +188,7 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
   u32x4 bring[R];
   auto bload = [&](int slot, int pos, int cc, bool live) {
     bring[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, live ? u_lane : BAD,
-                                                        pos * u_pos + cc * u_chunk, 0);
+                                                        pos * u_pos + (cbase + cc) * u_chunk, 0);
   };
 
   f32x4 acc[36];
@@ -236,21 +196,19 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
   for (int q = 0; q < 36; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < R; ++q) bload(q, q, 0, true);
-#ifdef SHAPY_W4_TOKEN
-  // (after the ring preload is in flight, before the first chunk barrier: the other waves of the
-  // workgroup wait at that barrier for this one)
-  int *tok = nullptr;
-  if (KC > 0 && KC <= SHAPY_W4_TOKEN && NW == 3 && wave == 0) {
-    tok = w4_token_slot();
-    if (lane == 0)
-      while (__hip_atomic_exchange(tok, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-        __builtin_amdgcn_s_sleep(8);
-    asm volatile("" ::: "memory");
-  }
-#endif
+  // split-K: this wave's reduction unit and its ticket (drawn in the last chunk)
+  Wino4Split sp;
+  sp.slab = p.split_ws; sp.slab_bytes = p.split_bytes; sp.slice = slice;
+  sp.unit = n_i * NW + wave; sp.n_units = p.nbx * NW;
+  sp.cnt = p.split_cnt + 2 * ((m_i * p.nbx + n_i) * NW + wave);
+  int ticket_v = 0;
 
   auto chunk = [&](int cc, bool more) {
     wino4_lds_barrier();                     // chunk cc is staged
+    if constexpr (S > 1) {
+      if (!more && lane == 0)
+        ticket_v = __hip_atomic_fetch_add(sp.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const char *Vb = lds + (cc & 1) * LDS_V + frag_off;
     u32x4 af[2][2];
     af[0][0] = *reinterpret_cast<const u32x4 *>(Vb + 0 * PSTR);
@@ -262,11 +220,6 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
         af[cur ^ 1][0] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 2) * PSTR);
         af[cur ^ 1][1] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 3) * PSTR);
       }
-#ifdef SHAPY_W4_PIN_AF
-      // the next pair's V fragments are REQUESTED before this pair's MFMAs (hipcc otherwise gives both
-      // pairs the same registers and sinks the reads behind the last MFMA that uses them)
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       // two positions interleaved: consecutive MFMAs hit different accumulators (40-cycle
       // dependent latency vs a 32-cycle issue interval)
       // A operand = filter fragment, B operand = V fragment: D[channel 4 g + r][tile l15]
@@ -277,7 +230,6 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
       // the slots the PREVIOUS pair consumed (lead R - 2 positions); pinned, or the compiler sinks
       // them to the end of the chunk.
       auto refill_prev = [&](int e) {
-        if (W4_DBG(8)) return;
         if (pp >= 2) {
           const int q = pp - 2 + e + R;
           if (q < 36) bload((pp - 2 + e) % R, q, cc, true);
@@ -291,7 +243,6 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
       };
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        if (W4_DBG(4) && kk > 0) break;
         acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(
             __uint_as_float(bring[pp % R][kk]), __uint_as_float(af[cur][0][kk]), acc[pp], 0, 0, 0);
         if (kk == 0 || kk == 2) {
@@ -313,24 +264,14 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_wino4_kernel(ConvK p) {
     for (int cc = 0; cc < CC; ++cc) chunk(cc, cc + 1 < CC);
   }
   wino4_lds_barrier();                       // barrier #CC: the staging wave's closing one
-#ifdef SHAPY_W4_TOKEN
-  if (tok && lane == 0) __hip_atomic_store(tok, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 
-#ifdef SHAPY_W4_PRIO_PARITY
-  __builtin_amdgcn_s_setprio(0);
-#endif
-  // ---- epilogue: output transform in registers, bias + residual + ReLU, 16-byte stores ----
-  // (conv_wino4.h; per lane: tile m_blk + l15, channels n0 + 4 g .. + 3)
+  // ---- epilogue: output transform in registers, (split-K exchange,) bias + residual + ReLU, 16-byte
+  // stores (conv_wino4.h; per lane: tile m_blk + l15, channels n0 + 4 g .. + 3)
   Wino4Epi e;
-  e.dbg = 0;
-#ifdef SHAPY_WINO_TIMING
-  e.dbg = p.dbg & 3;
-#endif
   e.out = p.out; e.res = p.res; e.in = p.in; e.bias = p.bias;
   e.H = H; e.W = W; e.tiles = T; e.out_ld = p.out_ld; e.out_coff = p.out_coff;
   e.res_ld = p.res_ld; e.res_coff = p.res_coff; e.relu = p.relu;
-  wino4_epilogue(e, acc, m_blk + l15, n0 + 4 * g);
+  wino4_epilogue<S>(e, sp, __builtin_amdgcn_readfirstlane(ticket_v), acc, m_blk + l15, n0 + 4 * g, g, lane);
 }
 
 // The kernel marks invalid accesses with the byte offset 0x40000000: every tensor it touches has
@@ -346,50 +287,56 @@ bool conv_wino4_fits(const ConvK &k) {
 }
 
 // tile flag 0x100000 of ShapyConv.tile: wgt_wino holds F(4x4,3x3) filters [36][Cin/16][Cout][16]
+// k.ksplit = S (SHAPY_TILE_W4_KSPLIT): K slices per output tile, 1 = none.  The instantiations below are
+// the ones a HRNet plan asks for (chunks per slice unrolled where the class is hot); any other S / shape
+// combination is SHAPY_EINVAL -- the plan, not the kernel, decides where splitting pays.
 int conv2d_wino4(ConvK k, hipStream_t s) {
   if (!conv_wino4_fits(k)) return SHAPY_EINVAL;
   const int B = k.M / (k.Ho * k.Wo);
   k.wino_tiles = B * ((k.Hi + 3) / 4) * ((k.Wi + 3) / 4);
   k.wgt2_bytes = (unsigned)(144ull * k.Cin * k.Cout);          // 36 positions x f32
   // 64-channel N tile (four multiplying waves, one workgroup per CU): layers whose Cout is no multiple of
-  // 48 (conv_wino4_fits: then Cout % 64 == 0), and on request (tile flag 0x400000, an A/B knob) those
-  // with BOTH -- 192 = 3 x 64, 384 = 6 x 64: all four SIMDs of a CU multiply
-  const bool n64 = k.Cout % 48 != 0 || (k.w4_n64 && k.Cout % 64 == 0);
-  k.nbx = k.Cout / (n64 ? 64 : 48);
+  // 48 (conv_wino4_fits: then Cout % 64 == 0)
+  const bool n64 = k.Cout % 48 != 0;
+  const int NW = n64 ? 4 : 3, S = k.ksplit < 1 ? 1 : k.ksplit;
+  k.nbx = k.Cout / (16 * NW);
   k.nby = (k.wino_tiles + 15) / 16;
-#ifdef SHAPY_WINO_TIMING
-  k.dbg = getenv("SHAPY_WINO_DBG") ? atoi(getenv("SHAPY_WINO_DBG")) : 0;
-  // occupancy experiment: unused dynamic LDS on top of the 72 KB, so that one workgroup fits a CU
-  const int dyn = getenv("SHAPY_WINO_DYN_LDS") ? atoi(getenv("SHAPY_WINO_DYN_LDS")) : 0;
-  if (dyn) {
-    (void)hipFuncSetAttribute((const void *)conv_wino4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
-    (void)hipFuncSetAttribute((const void *)conv_wino4_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
-    (void)hipFuncSetAttribute((const void *)conv_wino4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+  const int chunks = k.Cin / 16;
+  if (S > 1) {
+    // slab: S x (Cout / 16 wave units) x 16 pixels x tiles x 64 bytes; counters: 2 per (m tile, unit)
+    const unsigned long long slab = 64ull * 16 * k.wino_tiles * (k.Cout / 16) * S;
+    if (S > 4 || chunks % S || !k.split_ws || !k.split_cnt || ((uintptr_t)k.split_ws & 15) ||
+        slab > 0x40000000ull)
+      return SHAPY_EINVAL;
+    k.split_bytes = (unsigned)slab;
   }
-#else
-  const int dyn = 0;
-#endif
   // transformed filters larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
   if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt2_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
-  const dim3 grid(k.nbx * k.nby), blk(n64 ? 320 : 256);
+  const dim3 grid(k.nbx * k.nby * S), blk(64 * (NW + 1));
+  const int cps = chunks / S;                                    // chunks per slice
+#define W4_LAUNCH(KC, NWV, SV) hipLaunchKernelGGL((conv_wino4_kernel<KC, NWV, SV>), grid, blk, 0, s, k)
   if (n64) {
-    if (k.Cin == 64)
-      hipLaunchKernelGGL((conv_wino4_kernel<4, 4>), grid, blk, 0, s, k);
-    else
-      hipLaunchKernelGGL((conv_wino4_kernel<0, 4>), grid, blk, 0, s, k);
-    return (int)hipGetLastError();
+    if (S == 1 && cps == 4) W4_LAUNCH(4, 4, 1);
+    else if (S == 1) W4_LAUNCH(0, 4, 1);
+    else if (S == 2) W4_LAUNCH(0, 4, 2);
+    else if (S == 4) W4_LAUNCH(0, 4, 4);
+    else return SHAPY_EINVAL;
+  } else if (S == 1) {
+    if (cps == 3) W4_LAUNCH(3, 3, 1);
+    else if (cps == 6) W4_LAUNCH(6, 3, 1);
+    else W4_LAUNCH(0, 3, 1);
+  } else if (S == 2) {
+    if (cps == 12) W4_LAUNCH(12, 3, 2);
+    else if (cps == 6) W4_LAUNCH(6, 3, 2);
+    else W4_LAUNCH(0, 3, 2);
+  } else if (S == 3 && cps == 8) {
+    W4_LAUNCH(8, 3, 3);
+  } else if (S == 4 && cps == 6) {
+    W4_LAUNCH(6, 3, 4);
+  } else {
+    return SHAPY_EINVAL;
   }
-  if (k.Cin == 48)
-    hipLaunchKernelGGL(conv_wino4_kernel<3>, grid, blk, dyn, s, k);
-  else if (k.Cin == 96)
-    hipLaunchKernelGGL(conv_wino4_kernel<6>, grid, blk, dyn, s, k);
-  else if (k.Cin == 192 && k.w4_unroll12)
-    // A/B knob (tile flag 0x200000): bit-identical to the generic loop and no faster (40.9 vs
-    // 41.3 us at B = 64, profiles/r02y_wino4_unroll12_192.txt) -- the vmcnt(0) drain at the
-    // header of the generic loop is not what bounds the 192-channel class
-    hipLaunchKernelGGL(conv_wino4_kernel<12>, grid, blk, dyn, s, k);
-  else
-    hipLaunchKernelGGL(conv_wino4_kernel<0>, grid, blk, dyn, s, k);
+#undef W4_LAUNCH
   return (int)hipGetLastError();
 }
 

@@ -31,8 +31,6 @@
 // then exactly one per chunk, in the same global chunk order on both sides: the staging wave arrives
 // after writing chunk k, a multiplying wave before reading it.  The id of task t+1 is published in
 // an LDS mailbox before the barrier of task t's LAST chunk and read right after it.
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "conv_common.h"
@@ -54,31 +52,11 @@ struct W4Conv {
 struct W4Group {
   W4Conv c[4];
   int n;
-  int dbg;                 // tuning builds only (SHAPY_W4G_DBG)
-  int stagger;             // start delay of a CU's second workgroup, units of 128 clocks (conv_wino4.h)
   // schedule: slot s (= blockIdx.x / 8) of every XCD runs, for g = 0 .. n-1, the tasks
   // [first[g][s], first[g][s] + count[g][s]) of convolution g's per-XCD list (clipped to the
   // list's length on this XCD: lists differ by at most one task between XCDs)
   unsigned short count[4][64], first[4][64];
 };
-
-// Phase timing of one workgroup (tuning builds only: -DSHAPY_W4G_TIMING, read back with
-// shapy_debug_w4g_times; wall_clock64 ticks at 100 MHz).  Row 0: a multiplying wave, row 1: the
-// staging wave; every stamp is (tag << 56 | time).
-#ifdef SHAPY_W4G_TIMING
-__device__ unsigned long long g_w4g_times[2][128];
-__device__ int g_w4g_n[2];
-#define W4G_STAMP(row, tag)                                                                   \
-  do {                                                                                        \
-    if (blockIdx.x == (gridDim.x / 2 + 8) && (threadIdx.x & 63) == 0 && ((row) == 1 || threadIdx.x == 0)) { \
-      const int _i = g_w4g_n[row];                                                            \
-      if (_i < 128) g_w4g_times[row][_i] = ((unsigned long long)(tag) << 56) | (wall_clock64() & 0xffffffffffffffull); \
-      g_w4g_n[row] = _i + 1;                                                                  \
-    }                                                                                         \
-  } while (0)
-#else
-#define W4G_STAMP(row, tag) do {} while (0)
-#endif
 
 constexpr int W4G_BAD = 0x40000000;           // >= num_records of every buffer used here
 
@@ -119,7 +97,6 @@ __device__ __forceinline__ int w4g_task(const W4Group &G, const int task, int &g
   const int frag_off = l15 * 64 + (((g4 ^ l15 ^ (l15 >> 1)) & 3) << 4);
   const W4Conv &c = G.c[task >> 28];
   const int CC = c.Cin >> 4;
-  W4G_STAMP(0, 1);
   const W4Filt fc = w4g_filters(G, task, wave, l15, g4);
   const __amdgpu_buffer_rsrc_t rs_c =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(fc.ptr), 0, fc.bytes, 0x00020000);
@@ -139,9 +116,7 @@ __device__ __forceinline__ int w4g_task(const W4Group &G, const int task, int &g
   // this chunk's barrier
   auto chunk = [&](const int cc, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
-    W4G_STAMP(0, 2);
     wino4_lds_barrier();                     // chunk gc is staged
-    W4G_STAMP(0, 3);
     if constexpr (LAST) nxt = __builtin_amdgcn_readfirstlane(mbox[(tk + 1) & 1]);
     const char *Vb = lds + (gc & 1) * LDS_V + frag_off;
     u32x4 af[2][2];
@@ -154,11 +129,6 @@ __device__ __forceinline__ int w4g_task(const W4Group &G, const int task, int &g
         af[cur ^ 1][0] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 2) * PSTR);
         af[cur ^ 1][1] = *reinterpret_cast<const u32x4 *>(Vb + (pp + 3) * PSTR);
       }
-#ifdef SHAPY_W4_PIN_AF
-      // the next pair's V fragments are REQUESTED before this pair's MFMAs (hipcc otherwise gives both
-      // pairs the same registers and sinks the reads behind the last MFMA that uses them)
-      __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(
@@ -199,14 +169,12 @@ __device__ __forceinline__ int w4g_task(const W4Group &G, const int task, int &g
   // computes the 16 address registers below ahead of the K loop and spills them around it)
   int task_e = __builtin_amdgcn_readfirstlane(task);
   asm volatile("" : "+s"(task_e));
-  W4G_STAMP(0, 4);
   Wino4Epi e;
-  e.dbg = G.dbg;
   e.out = c.out; e.res = c.res; e.in = c.in; e.bias = c.bias;
   e.H = c.Hi; e.W = c.Wi; e.tiles = c.tiles; e.out_ld = c.out_ld; e.out_coff = c.out_coff;
   e.res_ld = c.res_ld; e.res_coff = c.res_coff; e.relu = c.relu;
-  wino4_epilogue(e, acc, (task_e & 0xfffff) * 16 + l15, ((task_e >> 20) & 0xff) * 48 + 16 * wave + 4 * g4);
-  W4G_STAMP(0, 5);
+  wino4_epilogue<1>(e, Wino4Split{}, 0, acc, (task_e & 0xfffff) * 16 + l15,
+                    ((task_e >> 20) & 0xff) * 48 + 16 * wave + 4 * g4, g4, lane);
   return nxt;
 }
 
@@ -266,10 +234,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino4g_kernel(W4Group G) {
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(row_off[i] + co), 0, 0));
     };
 
-#ifdef SHAPY_W4G_TIMING
-    if (blockIdx.x == (gridDim.x / 2 + 8) && lane == 0) g_w4g_n[0] = g_w4g_n[1] = 0;
-#endif
-    W4G_STAMP(1, 0);
     const int slot = blockIdx.x >> 3;
     int sg = 0, sk = 0;
     int cur = w4g_next_task(G, xcd, slot, sg, sk);
@@ -283,7 +247,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino4g_kernel(W4Group G) {
     }
     while (cur >= 0) {
       const int CC = CCn;
-      W4G_STAMP(1, 1);
       const int nxt = w4g_next_task(G, xcd, slot, sg, sk);
       for (int cc = 0; cc < CC; ++cc) {
         bool more = cc + 1 < CC;
@@ -333,9 +296,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4g_kernel(W4Group G) {
           if (more) gload_col(j, c0n);
           __builtin_amdgcn_sched_barrier(0);
         }
-        W4G_STAMP(1, 3);
         wino4_lds_barrier();                   // chunk gc is staged
-        W4G_STAMP(1, 4);
         ++gc;
       }
       cur = nxt;
@@ -345,10 +306,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino4g_kernel(W4Group G) {
   }
 
   // =========================== multiplying waves ===========================
-  wino4_start_stagger(G.stagger);
-#ifdef SHAPY_W4_PRIO
-  __builtin_amdgcn_s_setprio(SHAPY_W4_PRIO);
-#endif
   wino4_lds_barrier();                         // opening barrier
   int cur = __builtin_amdgcn_readfirstlane(mbox[0]);
   if (cur < 0) return;
@@ -370,13 +327,6 @@ int conv2d_wino4_group(const ConvK *ks, int n, hipStream_t s) {
   if (n < 1 || n > 4) return SHAPY_EINVAL;
   W4Group G;
   G.n = n;
-  G.dbg = 0;
-  G.stagger = 0;
-  for (int i = 0; i < n; ++i)
-    if (ks[i].w4_stagger > G.stagger) G.stagger = ks[i].w4_stagger;
-#ifdef SHAPY_W4G_TIMING
-  G.dbg = getenv("SHAPY_W4G_DBG") ? atoi(getenv("SHAPY_W4G_DBG")) : 0;
-#endif
   long tasks = 0;
   for (int i = 0; i < n; ++i) {
     const ConvK &k = ks[i];
@@ -427,11 +377,3 @@ int conv2d_wino4_group(const ConvK *ks, int n, hipStream_t s) {
 }
 
 }  // namespace shapy
-
-#ifdef SHAPY_W4G_TIMING
-extern "C" int shapy_debug_w4g_times(unsigned long long *out_host, int *n_host) {
-  int rc = (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(shapy::g_w4g_times), sizeof(unsigned long long) * 256);
-  if (rc) return rc;
-  return (int)hipMemcpyFromSymbol(n_host, HIP_SYMBOL(shapy::g_w4g_n), sizeof(int) * 2);
-}
-#endif

@@ -1,7 +1,5 @@
 // HRNet op-list executor + the two non-GEMM kernels of the backbone (stem conv, spatial mean).
 // Reference: regressor/human_shape/models/backbone/hrnet.py:426-498.
-#include <stdlib.h>
-
 #include <mutex>
 
 #include "common.h"
@@ -159,95 +157,11 @@ __global__ void mean_pool_kernel(const InT *__restrict__ in, float *__restrict__
   out[i] = s / (float)HW;
 }
 
-// ---- upsample terms of a fuse output in ONE pass (hrnet.py:181-191) ----
-// out = [relu](base [+ extra] [+ up2(y1) [+ up4(y2) [+ up8(y3)]]]), nearest upsampling, terms added in
-// this order.  base / out: [B, H, W] rows of `ld` elements (they may be the same tensor: a thread reads
-// and writes only its own 16 bytes); extra: dense [B, H, W, C] (the separately accumulated stride-2
-// terms of the output, fuse_add = 2 plans); y_t: dense [B, H >> (t+1), W >> (t+1), C].  A thread owns 16 bytes of a pixel
-// (4 floats / 8 bf16): every access is a full-width vector access, consecutive lanes are contiguous.
-// Replaces the upsample-scatter epilogue of the conv kernel for these layers (fuse_add plans): there the
-// FEW workgroups of the low-resolution GEMM (49 for the 7 x 7 source of a stage-4 module at B = 64, 196
-// for 14 x 14) each re-read and re-write UPS x UPS times their tile of the output, and the whole output
-// travels once per term -- 38 + 67 + 86 us for the three terms of the 56 x 56 output of a stage-4
-// module at B = 64 (profiles/r04o_timeline_*), a 20 us job by traffic.
-template <typename T>
-struct Vec16;
-template <>
-struct Vec16<float> {
-  static constexpr int N = 4;
-  static __device__ __forceinline__ void load(const float *p, float (&v)[4]) {
-    const f32x4 x = *reinterpret_cast<const f32x4 *>(p);
-    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
-  }
-  static __device__ __forceinline__ void store(float *p, const float (&v)[4]) {
-    *reinterpret_cast<f32x4 *>(p) = f32x4{v[0], v[1], v[2], v[3]};
-  }
-};
-template <>
-struct Vec16<unsigned short> {
-  static constexpr int N = 8;
-  static __device__ __forceinline__ void load(const unsigned short *p, float (&v)[8]) {
-    const u32x4 x = *reinterpret_cast<const u32x4 *>(p);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[2 * e] = __uint_as_float(x[e] << 16);
-      v[2 * e + 1] = __uint_as_float(x[e] & 0xffff0000u);
-    }
-  }
-  static __device__ __forceinline__ void store(unsigned short *p, const float (&v)[8]) {
-    store_row8(p, v);
-  }
-};
-
-template <typename T>
-__global__ __launch_bounds__(256) void fuse_add_kernel(const T *base, T *out,   // (may be one tensor)
-                                                       const T *__restrict__ extra,
-                                                       const T *__restrict__ y1,
-                                                       const T *__restrict__ y2,
-                                                       const T *__restrict__ y3, long n_vec, int H,
-                                                       int W, int C, int base_ld, int base_coff,
-                                                       int out_ld, int out_coff, int relu) {
-  constexpr int N = Vec16<T>::N;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_vec) return;
-  const int cv = C / N;                       // 16-byte vectors per pixel
-  const int c = (int)(i % cv) * N;
-  const long pix = i / cv;
-  const int x = (int)(pix % W);
-  const long q = pix / W;
-  const int y = (int)(q % H);
-  const long b = q / H;
-  float acc[N], t[N];
-  Vec16<T>::load(base + pix * base_ld + base_coff + c, acc);
-  if (extra) {
-    Vec16<T>::load(extra + pix * (long)C + c, t);
-#pragma unroll
-    for (int e = 0; e < N; ++e) acc[e] += t[e];
-  }
-  const T *ys[3] = {y1, y2, y3};
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    if (!ys[k]) break;
-    const int sh = k + 1;
-    const int Hk = H >> sh, Wk = W >> sh;
-    Vec16<T>::load(ys[k] + ((b * Hk + (y >> sh)) * Wk + (x >> sh)) * (long)C + c, t);
-#pragma unroll
-    for (int e = 0; e < N; ++e) acc[e] += t[e];
-  }
-  if (relu) {
-#pragma unroll
-    for (int e = 0; e < N; ++e) acc[e] = fmaxf(acc[e], 0.f);
-  }
-  Vec16<T>::store(out + pix * out_ld + out_coff + c, acc);
-}
-
 // ---- side streams for the independent branches of a HighResolutionModule ----
 constexpr int N_SIDE = 6;        // side streams: lanes 1..3 = branches, 4..6 = auxiliary chains
 constexpr int N_EVENTS = 64;     // dependency events (ShapyOp.sig / .wait), reused from epoch to epoch
 struct Lanes {
   hipStream_t s[N_SIDE] = {};
-  hipStream_t s0 = nullptr;        // SHAPY_LANE_CU_EIGHTHS experiment: lane 0 on a CU-masked stream of its own
-  hipEvent_t s0_in = nullptr, s0_out = nullptr;
   hipEvent_t fork = nullptr;
   hipEvent_t join[N_SIDE] = {};
   hipEvent_t ev[N_EVENTS] = {};
@@ -255,53 +169,19 @@ struct Lanes {
 };
 static Lanes g_lanes[16];
 static std::mutex g_lanes_mu;
+static std::mutex g_run_mu;      // held while a forward is enqueued (and by anybody else who touches the lanes)
 
 // Side stream of lane li + 1, created on first use: HIP spreads streams over a few hardware queues,
-// so streams that no plan uses (the auxiliary lanes 4..6 of the dag_aux experiment) should not exist.
-// (SHAPY_LANE_PRIO=0 turns the priorities off; +1.1..1.6 % end to end, run T of round 3) lane i + 1
-// (the branch with the smaller maps = the longer chain of latency-bound launches) gets a higher
-// stream priority than lane i.
-// EXPERIMENT (off unless SHAPY_LANE_CU_EIGHTHS is set; prepared at the end of round 4, never run):
-// "a,b,c,d" = how many eighths of the CUs the streams of lanes 0..3 may use (residue classes of the CU
-// index mod 8, handed out in this order; 0 = no mask).  In the traces the first launch of a small-map
-// lane waits 160-300 us for workgroup slots that the two large lanes' launches keep refilling
-// (profiles/r04o_module_tails.txt); a partition gives every lane slots of its own.  With a share for
-// lane 0 the executor runs lane 0 on an internal masked stream between a fork from and a join to the
-// caller's stream.  Masked streams carry no stream priority.
-static int lane_cu_share(int lane, uint32_t (&mask)[8]) {
-  static const char *env = getenv("SHAPY_LANE_CU_EIGHTHS");
-  if (!env || lane > 3) return 0;
-  int share[4] = {0, 0, 0, 0};
-  if (sscanf(env, "%d,%d,%d,%d", &share[0], &share[1], &share[2], &share[3]) < 1) return 0;
-  int first = 0;
-  for (int l = 0; l < lane; ++l) first += share[l] > 0 ? share[l] : 0;
-  const int n = share[lane];
-  if (n <= 0 || first + n > 8) return 0;
-  for (int w = 0; w < 8; ++w) {
-    mask[w] = 0;
-    for (int b = 0; b < 32; ++b) {
-      const int r = (w * 32 + b) & 7;
-      if (r >= first && r < first + n) mask[w] |= 1u << b;
-    }
-  }
-  return n;
-}
-
+// so streams that no plan uses should not exist.  Lane i + 1 (the branch with the smaller maps = the
+// longer chain of latency-bound launches) gets a higher stream priority than lane i (+1.1..1.6 % end
+// to end, run T of round 3).
 static int lane_stream(Lanes *L, int li, hipStream_t *out) {
   if (!L->s[li]) {
-    static const int prio_mode = getenv("SHAPY_LANE_PRIO") ? atoi(getenv("SHAPY_LANE_PRIO")) : 1;
-    uint32_t mask[8];
-    if (lane_cu_share(li + 1, mask)) {
-      SHAPY_HIP_TRY(hipExtStreamCreateWithCUMask(&L->s[li], 8, mask));
-    } else if (prio_mode) {
-      int plo = 0, phi = 0;
-      SHAPY_HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi));    // phi = highest (numerically lowest)
-      int pr = plo - (li % 3 + 1);
-      if (pr < phi) pr = phi;
-      SHAPY_HIP_TRY(hipStreamCreateWithPriority(&L->s[li], hipStreamNonBlocking, pr));
-    } else {
-      SHAPY_HIP_TRY(hipStreamCreateWithFlags(&L->s[li], hipStreamNonBlocking));
-    }
+    int plo = 0, phi = 0;
+    SHAPY_HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi));    // phi = highest (numerically lowest)
+    int pr = plo - (li % 3 + 1);
+    if (pr < phi) pr = phi;
+    SHAPY_HIP_TRY(hipStreamCreateWithPriority(&L->s[li], hipStreamNonBlocking, pr));
   }
   *out = L->s[li];
   return SHAPY_OK;
@@ -325,37 +205,32 @@ static int get_lanes(Lanes **out) {
   return SHAPY_OK;
 }
 
+// The side stream of `lane` (1 .. N_SIDE) on the current device, created on first use: lets the host
+// put work of its own -- the betas all-gather of a data-parallel step -- on a stream the process
+// already has instead of adding one (every extra stream costs the four-lane forward).
+int hrnet_lane_stream(int lane, hipStream_t *out) {
+  if (lane < 1 || lane > N_SIDE || !out) return SHAPY_EINVAL;
+  Lanes *L = nullptr;
+  std::lock_guard<std::mutex> lk(g_run_mu);
+  const int rc = get_lanes(&L);
+  if (rc) return rc;
+  return lane_stream(L, lane - 1, out);
+}
+
 int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *input, void *ws,
-              int64_t ws_per_img, float *features_out, int B, int H, int W, int multi_stream,
-              int dtype, hipStream_t main) {
+              int64_t ws_per_img, int32_t *counters, int64_t cnt_per_img, float *features_out, int B,
+              int H, int W, int multi_stream, int dtype, hipStream_t main) {
   const int esz = dtype == SHAPY_DTYPE_BF16 ? 2 : 4;
   const float *wf32 = reinterpret_cast<const float *>(weights);   // biases + stem weights
   Lanes *L = nullptr;
   // The side streams and their fork / join events are one set per device, shared by every
   // caller: the whole issue of a forward (and a graph capture of it) holds this lock, so two host
   // threads or two caller streams cannot interleave their fork / join records on them.
-  static std::mutex run_mu;
-  std::unique_lock<std::mutex> run_lock(run_mu, std::defer_lock);
+  std::unique_lock<std::mutex> run_lock(g_run_mu, std::defer_lock);
   if (multi_stream) {
     run_lock.lock();
     int rc = get_lanes(&L);
     if (rc) return rc;
-  }
-  // lane 0 = the caller's stream -- unless the CU-partition experiment gives lane 0 a share: then an
-  // internal masked stream that starts behind the caller's stream here and is joined to it at the end
-  hipStream_t caller = main;
-  if (multi_stream) {
-    uint32_t mask[8];
-    if (lane_cu_share(0, mask)) {
-      if (!L->s0) {
-        SHAPY_HIP_TRY(hipExtStreamCreateWithCUMask(&L->s0, 8, mask));
-        SHAPY_HIP_TRY(hipEventCreateWithFlags(&L->s0_in, hipEventDisableTiming));
-        SHAPY_HIP_TRY(hipEventCreateWithFlags(&L->s0_out, hipEventDisableTiming));
-      }
-      SHAPY_HIP_TRY(hipEventRecord(L->s0_in, caller));
-      SHAPY_HIP_TRY(hipStreamWaitEvent(L->s0, L->s0_in, 0));
-      main = L->s0;
-    }
   }
   bool forked[N_SIDE] = {}, dirty[N_SIDE] = {};
   auto join_all = [&]() -> int {
@@ -365,13 +240,6 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
         SHAPY_HIP_TRY(hipStreamWaitEvent(main, L->join[i], 0));
         dirty[i] = false;
       }
-    return SHAPY_OK;
-  };
-  auto leave = [&]() -> int {            // internal lane-0 stream -> the caller's stream
-    if (main != caller) {
-      SHAPY_HIP_TRY(hipEventRecord(L->s0_out, main));
-      SHAPY_HIP_TRY(hipStreamWaitEvent(caller, L->s0_out, 0));
-    }
     return SHAPY_OK;
   };
   bool fork_recorded = false;
@@ -439,6 +307,10 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
       d.res_coff = q.res_coff; d.relu = q.relu; d.ups = q.ups; d.tile = q.tile;
       d.reserved0 = 0;
       d.wgt_wino = (dtype == SHAPY_DTYPE_F32 && q.wino_off >= 0) ? wf32 + q.wino_off : nullptr;
+      // split-K layers: slab in the workspace, arrival counters in the caller's counter array
+      d.split_ws = buf(q.split_off);
+      d.split_cnt = (counters && q.cnt_off >= 0 && q.cnt_off < cnt_per_img) ? counters + q.cnt_off * (int64_t)B
+                                                                            : nullptr;
     };
     if (o.type == SHAPY_OP_CONV) {
       int rc = SHAPY_OK;
@@ -466,10 +338,7 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
         rc = conv2d(d, s);
       }
       if (rc) {
-        if (multi_stream) {                  // leave no forked lane unjoined behind an error
-          join_all();
-          leave();
-        }
+        if (multi_stream) join_all();        // leave no forked lane unjoined behind an error
         return rc;
       }
     } else if (o.type == SHAPY_OP_STEM) {
@@ -498,32 +367,6 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
                            (const unsigned short *)buf(o.in_off), features_out, o.Hi * o.Wi, o.Cin,
                            o.in_ld, total);
       SHAPY_HIP_TRY(hipGetLastError());
-    } else if (o.type == SHAPY_OP_FUSEADD) {
-      // Ho x Wo x Cout output; res = the base tensor; wino_off = a second full-resolution term (-1:
-      // none); in_off / wgt_off / bias_off = the up to three low-resolution terms -- all offsets into
-      // the WORKSPACE (upsample factors 2, 4, 8; ksize = how many, 0..3)
-      const int nv = esz == 4 ? 4 : 8;
-      if (o.ksize < 0 || o.ksize > 3 || o.res_off < 0 || o.out_off < 0 || (o.ksize > 0 && o.in_off < 0) ||
-          (o.ksize > 1 && o.wgt_off < 0) || (o.ksize > 2 && o.bias_off < 0) || o.Cout % nv ||
-          o.out_ld % nv || o.out_coff % nv || o.res_ld % nv || o.res_coff % nv ||
-          (o.Ho & ((1 << o.ksize) - 1)) || (o.Wo & ((1 << o.ksize) - 1)))
-        return SHAPY_EINVAL;
-      const long n_vec = (long)B * o.Ho * o.Wo * (o.Cout / nv);
-      const dim3 grid((unsigned)((n_vec + 255) / 256));
-      char *y1 = o.ksize > 0 ? buf(o.in_off) : nullptr, *y2 = o.ksize > 1 ? buf(o.wgt_off) : nullptr,
-           *y3 = o.ksize > 2 ? buf(o.bias_off) : nullptr, *ex = buf(o.wino_off);
-      if (esz == 4)
-        hipLaunchKernelGGL(fuse_add_kernel<float>, grid, dim3(256), 0, s, (const float *)buf(o.res_off),
-                           (float *)buf(o.out_off), (const float *)ex, (const float *)y1, (const float *)y2,
-                           (const float *)y3, n_vec, o.Ho, o.Wo, o.Cout, o.res_ld, o.res_coff, o.out_ld,
-                           o.out_coff, o.relu);
-      else
-        hipLaunchKernelGGL(fuse_add_kernel<unsigned short>, grid, dim3(256), 0, s,
-                           (const unsigned short *)buf(o.res_off), (unsigned short *)buf(o.out_off),
-                           (const unsigned short *)ex, (const unsigned short *)y1, (const unsigned short *)y2,
-                           (const unsigned short *)y3, n_vec, o.Ho, o.Wo, o.Cout, o.res_ld, o.res_coff,
-                           o.out_ld, o.out_coff, o.relu);
-      SHAPY_HIP_TRY(hipGetLastError());
     } else {
       return SHAPY_EINVAL;
     }
@@ -536,9 +379,7 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
         }
   }
   if (multi_stream) {
-    int rc = join_all();
-    if (rc) return rc;
-    rc = leave();
+    const int rc = join_all();
     if (rc) return rc;
   }
   return SHAPY_OK;

@@ -35,8 +35,8 @@ BN_MOMENTUM = 0.1
 #: product defaults of HighResolutionNet.conv_algo / .wino4_min_hw (see there)
 DEFAULT_CONV_ALGO = 'winograd4'
 DEFAULT_WINO4_MIN_HW = 7
-DEFAULT_WINO4_N64 = '0'
-DEFAULT_FUSE_ADD = '0'          # 0 | 1 | 2 (HighResolutionNet.fuse_add)
+#: F(4x4) split-K (csrc/conv_wino4.hip): {(Cin, most 4x4 tiles per image): K slices}
+DEFAULT_WINO4_KSPLIT = {(384, 4): 2}
 
 
 # ------------------------------------------------------------------------------------------
@@ -186,7 +186,7 @@ class _Plan:
         self.wbytes = 0
         self.epoch = 0
         self._pending_barrier = False
-        self.no_barriers = False
+        self.cnt_ints = 0      # split-K arrival counters (int32 per image) handed out so far
         self._group_left = 0   # ops still to come in the current launch group
         self._group_t = 0      # ... and the group's time index (= op index of its first op)
 
@@ -202,9 +202,7 @@ class _Plan:
         return b
 
     def barrier(self):
-        # (event-driven plans order the lanes by data dependencies alone: no joins)
-        if not self.no_barriers:
-            self._pending_barrier = True
+        self._pending_barrier = True
 
     def add_weights(self, arr, as_bf16=False):
         """Appends a tensor to the weight blob; returns its offset in ELEMENTS of its own type
@@ -252,7 +250,7 @@ class _Plan:
             t = len(self.ops)
             if kw['group'] > 1:
                 self._group_left, self._group_t = kw['group'] - 1, t
-        for key in ('inb', 'outb', 'resb', 'inb2', 'inb3', 'inb4'):
+        for key in ('inb', 'outb', 'resb', 'scrb'):
             b = kw.get(key)
             if b is not None:
                 b.uses.append((self.epoch, kw['lane'], t))
@@ -260,9 +258,10 @@ class _Plan:
         # residual: the output's slice), write-after-read / -write on the slice written
         i, deps = len(self.ops), set()
         acc = []
-        for key in ('inb', 'inb2', 'inb3', 'inb4'):  # (inb2 .. inb4: the further terms of a FUSEADD op)
-            if kw.get(key) is not None:
-                acc.append((kw[key], False, 0, kw[key].C))
+        if kw.get('inb') is not None:
+            acc.append((kw['inb'], False, 0, kw['inb'].C))
+        if kw.get('scrb') is not None:               # split-K slab: private scratch, written
+            acc.append((kw['scrb'], True, 0, kw['scrb'].C))
         if kw.get('resb') is not None:
             acc.append((kw['resb'], False, kw['res_coff'], kw['res_coff'] + kw['Cout']))
         if kw.get('outb') is not None:
@@ -458,8 +457,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.tile_overrides = {}
         self.tile_flags = 0          # OR-ed into every conv's tile id (tuning knobs)
         #: replay the forward as one hipGraph (csrc/capi.hip) instead of ~330 launches: True (the
-        #: captured barrier plan), 'explicit' (the event-driven plan as a hand-built graph:
-        #: shapy_hrnet_graph_create_explicit), False, or 'auto' = True for batches up to graph_max_batch
+        #: captured barrier plan), False, or 'auto' = True for batches up to graph_max_batch
         self.use_graph = 'auto'
         #: round 3: 0 = 'auto' never captures -- with the event-driven plan and lane priorities the
         #: eager forward is faster than the replay at every batch size (B = 1: 5.5 vs 6.3 ms, B = 8:
@@ -473,13 +471,9 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: 1e-4 parity tests for all of them):
         #:   'winograd4' (default) = Winograd F(4x4,3x3) (csrc/conv_wino4.hip: 36 multiplies per
         #:       4x4 outputs, 48-channel N tiles) on maps of at least wino4_min_hw pixels a side,
-        #:       F(2x2,3x3) on the rest.  Measured on MI355X at B = 64 (profiles/
-        #:       conv_bench_r02w_wino_vs_wino4.txt): 61 -> 51 us (48 ch @56x56), 59 -> 40 us (96 ch
-        #:       @28x28), 58 -> 42 us (192 ch @14x14), but 62 -> 69 us on the 7x7 maps (256 tiles
-        #:       cannot fill the chip): hence 14; end to end 3,808 -> 4,473 images/s
+        #:       F(2x2,3x3) on the rest
         #:   'winograd' = Winograd F(2x2,3x3) (csrc/conv_wino.hip, 2.25x fewer MFMAs than direct)
-        #:       wherever the kernel applies -- faster than direct on every eligible HRNet class
-        #:       incl. the 7x7 maps (profiles/conv_bench_r02*)
+        #:       wherever the kernel applies
         #:   'direct' = implicit GEMM for every layer (the exact-f32 fmaf chain of the reference's
         #:       sum order)
         #:   'auto' = F(2x2) only on maps of at least wino_min_hw pixels a side
@@ -488,65 +482,49 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.conv_algo = os.environ.get('SHAPY_CONV_ALGO', DEFAULT_CONV_ALGO)
         self.wino_min_hw = 14
         self.wino4_min_hw = int(os.environ.get('SHAPY_WINO4_MIN_HW', DEFAULT_WINO4_MIN_HW))
-        #: conv_algo='winograd4': layers whose Cout is a multiple of 64 but not of 48 on the 64-channel
-        #: variant of the F(4x4) kernel (four multiplying waves, one workgroup per CU) instead of
-        #: F(2x2), on maps of at least wino4_n64_min_hw pixels a side (= layer1's four 64 -> 64 convs).
-        #: OFF by default: the kernel is 15 % faster on that class in isolation (88 vs 104 us) but the
-        #: forward does not move (5,091 vs 5,082 images/s, three interleaved runs each,
-        #: profiles/r04t_*), and on the head's 512 -> 512 @7x7 it loses (131 vs 100 us)
-        self.wino4_n64 = os.environ.get('SHAPY_WINO4_N64', DEFAULT_WINO4_N64) == '1'
-        self.wino4_n64_min_hw = int(os.environ.get('SHAPY_WINO4_N64_MIN_HW', '28'))
-        #: F(4x4) layers with these output widths (multiples of 48 AND of 64: 192, 384) on the
-        #: 64-channel N tile -- all four SIMDs of a CU multiply, one workgroup per CU, 25 % fewer
-        #: workgroups.  An A/B knob (SHAPY_WINO4_N64_COUT="192,384"), empty = off; prepared at the
-        #: end of round 4: in the stage-4 branch phases the chip runs at 82-85 % of what THREE
-        #: multiplying SIMDs per CU can do, the fourth is the next third
-        self.wino4_n64_cout = tuple(int(c) for c in os.environ.get('SHAPY_WINO4_N64_COUT', '').split(',') if c)
-        #: the upsample terms of a fuse output (reference hrnet.py:181-191: 1x1 conv + BN + nearest
-        #: Upsample, added to the output) as plain low-resolution convs + ONE add pass over the output
-        #: (SHAPY_OP_FUSEADD) instead of one upsample-scatter conv per term.  Written at the end of
-        #: round 4 from the timeline (191 us of scatter epilogues per stage-4 module on the critical
-        #: lane, a 20 us job by traffic) after the GPU budget was spent: OFF until it has run on
-        #: hardware (tests/test_zz_fuse_add_gpu.py is its first run; the plan and its arithmetic are
-        #: checked on the CPU by tests/test_plan_replay.py)
-        #: 2 additionally takes x_i out of the accumulation: the stride-2
-        #: terms of output i are accumulated into a buffer of their own in the order their sources
-        #: become ready (x0 last), on lanes that are idle by then (fuse_chain_lanes, per stage:
-        #: 'dest' = the lane of the output, 'source' = the lane of the input branch, 'mixed' = dest
-        #: except for the last branch), and out_i = relu(x_i + T_i + upsample terms) is ONE short add
-        #: behind the last branch to finish -- in the traces the 7x7 lane of a stage-4 module ends last
-        #: and then runs 155-210 us of accumulating convs that had their inputs long before
-        #: (profiles/r04o_timeline_*_verbose.txt).  Same status as 1: CPU-checked, not yet run.
-        self.fuse_add = int(os.environ.get('SHAPY_FUSE_ADD', DEFAULT_FUSE_ADD))
-        self.fuse_chain_lanes = os.environ.get('SHAPY_FUSE_CHAIN_LANES', 'dest,dest,mixed')
+        #: conv_algo='winograd4': output widths that are a multiple of 64 but not of 48 and may run on
+        #: the 64-channel variant of the F(4x4) kernel (four multiplying waves, one workgroup per CU)
+        #: instead of F(2x2).  Empty by default: on layer1's 64 -> 64 it is 15 % faster in isolation
+        #: (88 vs 104 us) but the forward does not move (profiles/r04t_*); on the head's 512 -> 512
+        #: @7x7 it loses without a K split (131 vs 100 us).  (SHAPY_WINO4_N64="64,512" for A/B runs.)
+        self.wino4_n64 = tuple(int(c) for c in os.environ.get('SHAPY_WINO4_N64', '').split(',') if c)
+        #: F(4x4) split-K: {(Cin, most 4x4 tiles per image): S} -- a layer with that many input channels
+        #: on a map of at most that many tiles runs S workgroups per output tile, each over Cin / S
+        #: channels (csrc/conv_wino4.hip).  For the K-deep layers on the small maps: 384 -> 384 @7x7 is
+        #: 128 workgroups of 24 chunks at B = 64.  The choice depends on the layer alone, never on the
+        #: batch: features stay bit-identical across batch sizes.  (SHAPY_W4_KSPLIT="384@4:2,192@16:2"
+        #: overrides it for A/B runs; "" = no split anywhere.)
+        self.wino4_ksplit = dict(DEFAULT_WINO4_KSPLIT)
+        if 'SHAPY_W4_KSPLIT' in os.environ:
+            self.wino4_ksplit = {}
+            for item in filter(None, os.environ['SHAPY_W4_KSPLIT'].split(',')):
+                key, sl = item.split(':')
+                cin, tmax = key.split('@')
+                self.wino4_ksplit[(int(cin), int(tmax))] = int(sl)
 
         #: conv_algo='winograd4': the convs at the same depth of a HighResolutionModule's parallel
         #: branches as ONE persistent grouped launch (csrc/conv_wino4g.hip) instead of one launch
-        #: per branch on its own stream; bit-identical features either way
+        #: per branch on its own stream
         #: 'auto' (default) = only when the forward runs on ONE stream: on four streams the per-layer
         #: launches overlap the fuse layers of a module with the first convs of the next and are the
         #: faster configuration at every batch size measured (B = 64: 4,745 vs 4,662 images/s; one
         #: stream: 14.1 vs 16.3 ms per step in favour of the groups; profiles/r03m_*)
         self.group_branches = {'1': True, '0': False}.get(os.environ.get('SHAPY_GROUP_BRANCHES', ''), 'auto')
-        #: Winograd numerics guard: per-layer demotions {op name: 'winograd' (F(2x2)) | 'direct'} found
-        #: by ``calibrate`` for the CURRENT weights; wino_guard = run the calibration on the first
-        #: float32 batch after the weights changed (SHAPY_WINO_GUARD=0 disables)
         #: multi-stream plans: explicit dependencies (events) instead of a join between the branches
-        #: and the fuse layers of a module, fuse chains on auxiliary lanes (SHAPY_DAG=0: round-2 plan)
-        self.dag = os.environ.get('SHAPY_DAG', '1') != '0'
-        self.dag_aux = os.environ.get('SHAPY_DAG_AUX', '0') == '1'
-        self.dag_no_barriers = os.environ.get('SHAPY_DAG_NO_BARRIERS', '0') == '1'
-        self.dag_balance = os.environ.get('SHAPY_DAG_BALANCE', '0') == '1'
-        #: per-layer demotions {op name: 'winograd' (F(2x2)) | 'direct'}: the caller's own entries AND
-        #: what the guard added for the current weights (the guard never removes a caller's entry)
+        #: and the fuse layers of a module (False: the round-2 barrier plan)
+        self.dag = True
+        #: Winograd numerics guard: per-layer demotions {op name: 'winograd' (F(2x2)) | 'direct'}: the
+        #: caller's own entries AND what ``calibrate`` added for the CURRENT weights (the guard never
+        #: removes a caller's entry); wino_guard = run the calibration on the first float32 batch after
+        #: the weights changed (SHAPY_WINO_GUARD=0 disables)
         self.layer_algo = {}
-        self._guard_demotions = {}       # the guard's share of layer_algo (dropped on re-calibration)
+        self._guard_demotions = {}       # name -> (the guard's value, the caller's entry it replaced | None)
         self.wino_guard = os.environ.get('SHAPY_WINO_GUARD', '1') != '0'
         self.wino_budget = 2e-5          # rms(winograd - direct) / rms(direct) per layer
         #: probe of the automatic calibration: 'fixed' (default) = four SEEDED synthetic crops of the
         #: input's size -- the same on every rank and in every run, so that all ranks compile the same
         #: plan and features stay bit-identical between them; 'batch' = up to 8 images of the first
-        #: batch (round 3).  ``calibrate(x)`` on images of your own is always available.
+        #: batch.  ``calibrate(x)`` on images of your own is always available.
         self.wino_guard_probe = os.environ.get('SHAPY_WINO_GUARD_PROBE', 'fixed')
         #: runtime tripwire: > 0 = every that many forwards two images of the LIVE batch are re-checked
         #: layer by layer (one extra pass over the op list with host syncs: ~30 ms) and layers over
@@ -684,24 +662,30 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         return self.conv_algo in ('winograd', 'winograd4') or min(Hi, Wi) >= self.wino_min_hw
 
     def _use_wino4(self, ks, st, pad, cin, cout, Hi, Wi, ups):
-        # 64-channel N tiles (four multiplying waves, one workgroup per CU): only where they beat
-        # F(2x2) -- 88 vs 104 us on layer1's 64 -> 64 @56x56, but 131 vs 100 us on the head's
-        # 512 -> 512 @7x7 (128 workgroups of 32 chunks; profiles/r04s_*)
-        if cout % 48 and not (self.wino4_n64 and min(Hi, Wi) >= self.wino4_n64_min_hw):
+        # 64-channel N tiles (four multiplying waves, one workgroup per CU): only on request
+        if cout % 48 and cout not in self.wino4_n64:
             return False
         return (self.conv_algo == 'winograd4' and min(Hi, Wi) >= self.wino4_min_hw
                 and winograd.eligible4(ks, st, pad, cin, cout, ups))
 
+    def _ksplit(self, cin, Hi, Wi):
+        """K slices of an F(4x4) layer (``wino4_ksplit``); 1 = no split."""
+        t = ((Hi + 3) // 4) * ((Wi + 3) // 4)
+        best = 1
+        for (c, tmax), sl in self.wino4_ksplit.items():
+            if c == cin and t <= tmax and (cin // 16) % sl == 0:
+                best = max(best, int(sl))
+        return best
+
     def _build_plan(self, H, W, bf16=False, x6=False):
         P = _Plan(bf16, x6)
-        P.no_barriers = bool(self._dag_eff and self.dag_no_barriers and not self._group_on())
         ov = self.tile_overrides
-        lane_load = {}
         if self.conv_algo not in ('direct', 'winograd', 'winograd4', 'auto'):
             raise ValueError(f'unknown conv_algo {self.conv_algo!r}')
 
         def conv(conv_m, bn, inb, Hi, Wi, outb=None, res=None, relu=False, ups=1, lane=0,
-                 out_ld=None, out_coff=0, res_ld=None, res_coff=0, name='', group=0):
+                 out_ld=None, out_coff=0, res_ld=None, res_coff=0, name='', group=0,
+                 group_member=False):
             ks, st, pad = conv_m.kernel_size[0], conv_m.stride[0], conv_m.padding[0]
             cin, cout = conv_m.in_channels, conv_m.out_channels
             cin_p, cout_p = P.padc(cin), P.padc(cout)
@@ -717,6 +701,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             if outb is None:
                 outb = P.buf(Ho * ups, Wo * ups, cout_p)
             wino_off, wino_flag = -1, 0
+            scrb, cnt_off = None, -1
             forced = self.layer_algo.get(name)       # Winograd guard (calibrate): per-layer demotion
             if forced == 'direct':
                 pass
@@ -725,18 +710,17 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             elif not (bf16 or x6) and self._use_wino4(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
                 wino_off = P.add_weights(winograd.transform_filters4(w))
                 wino_flag = _lib.TILE_WINO4
-                if cout_p in self.wino4_n64_cout and cout_p % 64 == 0:
-                    wino_flag |= _lib.TILE_WINO4_N64
+                # split-K (never inside a persistent grouped launch, which has no such form)
+                sl = 1 if group_member else self._ksplit(cin_p, Hi, Wi)
+                if sl > 1:
+                    slab, ncnt = _lib.w4_split_sizes(Hi, Wi, cout_p, sl)
+                    scrb = P.buf(1, 1, slab)
+                    cnt_off, P.cnt_ints = P.cnt_ints, P.cnt_ints + ncnt
+                    wino_flag |= _lib.tile_w4_ksplit(sl)
             elif not (bf16 or x6) and self._use_wino(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
                 wino_off = P.add_weights(winograd.transform_filters(w))
-            # rough cost of the launch under the usual four-stream contention (us): picks the lane of
-            # the fuse chains' leading convs (module(): least loaded lane)
-            # (timeline at B = 64: every branch conv of a module takes 105-150 us whatever its map
-            # size -- the small maps are latency-bound chains --, the direct layers 15 us + 45 TFLOP/s)
-            macs = Ho * Wo * cout_p * cin_p * ks * ks
-            lane_load[lane] = lane_load.get(lane, 0.0) + (
-                110.0 if wino_off >= 0 else 15.0 + 2.0 * 64 * macs / 45e6)
-            P.op(type=_lib.OP_CONV, lane=lane, inb=inb, outb=outb, resb=res, Hi=Hi, Wi=Wi, Cin=cin_p,
+            P.op(type=_lib.OP_CONV, lane=lane, inb=inb, outb=outb, resb=res, scrb=scrb, cnt_off=cnt_off,
+                 Hi=Hi, Wi=Wi, Cin=cin_p,
                  in_ld=inb.C, Ho=Ho, Wo=Wo, Cout=cout_p, ksize=ks, stride=st, pad=pad,
                  out_ld=out_ld or outb.C, out_coff=out_coff,
                  res_ld=(res_ld or (res.C if res is not None else 0)), res_coff=res_coff,
@@ -790,54 +774,10 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 x, Hc, Wc = conv(s[0], s[1], x, Hc, Wc, relu=True, lane=lane, name=f'{name}.{q}')
             return x, Hc, Wc
 
-        def fuse_deferred(m, ys, last_out, name, stage):
-            """fuse_add = 2: out_i = relu(x_i + T_i + sum_{j>i} up(y_ij)); T_i = the stride-2 terms of
-            output i accumulated in a buffer of their own, sources in the order they become ready."""
-            nb = m.num_branches
-            pol = (self.fuse_chain_lanes.split(',') + ['dest'] * 3)[stage]
-            if pol not in ('dest', 'source', 'mixed'):
-                raise ValueError(f'fuse_chain_lanes: unknown policy {pol!r}')
-            low = {}
-            for i in range(nb):
-                for j in range(i + 1, nb):
-                    xj, Hj, Wj = ys[j]
-                    fl = m.fuse_layers[i][j]
-                    low[(i, j)], _, _ = conv(fl[0], fl[1], xj, Hj, Wj, lane=j,
-                                             name=f'{name}.fuse_layers.{i}.{j}')
-            T, started = {i: P.buf(ys[i][1], ys[i][2], ys[i][0].C) for i in range(1, nb)}, set()
-            for j in range(nb - 2, -1, -1):          # sources: the small maps first, x0 last
-                for i in range(j + 1, nb):
-                    lane = i if (pol == 'dest' or (pol == 'mixed' and i < nb - 1)) else j
-                    fl = m.fuse_layers[i][j]
-                    t, Ht, Wt = ys[j]
-                    for k in range(i - j - 1):
-                        t, Ht, Wt = conv(fl[k][0], fl[k][1], t, Ht, Wt, relu=True, lane=lane,
-                                         name=f'{name}.fuse_layers.{i}.{j}.{k}')
-                    k = i - j - 1
-                    conv(fl[k][0], fl[k][1], t, Ht, Wt, outb=T[i], res=T[i] if i in started else None,
-                         relu=False, lane=lane, name=f'{name}.fuse_layers.{i}.{j}.{k}')
-                    started.add(i)
-            outs = []
-            for i in range(nb):
-                xi, Hi_, Wi_ = ys[i]
-                use_last = last_out is not None and i == nb - 1
-                outb = last_out[0] if use_last else P.buf(Hi_, Wi_, xi.C)
-                o_ld = last_out[1] if use_last else xi.C
-                o_co = last_out[2] if use_last else 0
-                ups_terms = [low[(i, j)] for j in range(i + 1, nb)] + [None] * 3
-                P.op(type=_lib.OP_FUSEADD, lane=i, inb=ups_terms[0], inb2=ups_terms[1],
-                     inb3=ups_terms[2], inb4=T.get(i), outb=outb, resb=xi, Hi=Hi_, Wi=Wi_, Cin=xi.C,
-                     in_ld=xi.C, Ho=Hi_, Wo=Wi_, Cout=xi.C, ksize=nb - 1 - i, stride=1, pad=0,
-                     out_ld=o_ld, out_coff=o_co, res_ld=xi.C, res_coff=0, relu=1, ups=2, tile=0,
-                     wgt_off=-1, bias_off=-1, wino_off=-1, name=f'{name}.fuse_add.{i}')
-                outs.append((outb, Hi_, Wi_))
-            return outs
-
-        def module(m, xs, last_out=None, name='', stage=0):
+        def module(m, xs, last_out=None, name=''):
             """xs: list of (buf, H, W).  HighResolutionModule.forward (hrnet.py:175-193)."""
             nb = m.num_branches
             ys = []
-            lane_load.clear()               # per module: the choice below balances THIS module's lanes
             depth = len(m.branches[0])
             grouped = (self._group_on() and not (bf16 or x6) and 2 <= nb <= 4
                        and all(len(br) == depth for br in m.branches)
@@ -858,14 +798,14 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                         blk = m.branches[i][bi]
                         t, _, _ = conv(blk.conv1, blk.bn1, cur[i], xs[i][1], xs[i][2], relu=True,
                                        lane=0, name=f'{name}.branches.{i}.{bi}.conv1',
-                                       group=nb if i == 0 else 0)
+                                       group=nb if i == 0 else 0, group_member=True)
                         ts.append(t)
                     for i in range(nb):
                         blk = m.branches[i][bi]
                         cur[i], _, _ = conv(blk.conv2, blk.bn2, ts[i], xs[i][1], xs[i][2],
                                             res=cur[i], relu=True, lane=0,
                                             name=f'{name}.branches.{i}.{bi}.conv2',
-                                            group=nb if i == 0 else 0)
+                                            group=nb if i == 0 else 0, group_member=True)
                 ys = [(cur[i], xs[i][1], xs[i][2]) for i in range(nb)]
             else:
                 for i in range(nb):
@@ -878,15 +818,12 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                     ys.append((x, Hc, Wc))
             # dag: no join between the branches and the fuse layers -- every fuse conv waits for
             # exactly the tensors it reads (events, _Plan.sync_plan) -- and the leading convs of the
-            # stride-2 chains (fuse_layers[i][j], i - j >= 2) run on auxiliary lanes 4..6, so that
-            # the output of the smallest map no longer queues six convs on one stream
+            # stride-2 chains (fuse_layers[i][j], i - j >= 2) run on the lane of their SOURCE branch
+            # (free as soon as that branch is done), so that the output of the smallest map no longer
+            # queues six convs on one stream
             dag = self._dag_eff and not grouped
             if not dag:
                 P.barrier()
-            fadd = int(self.fuse_add)
-            if fadd == 2:                   # (cross-lane order by dependency events in every kind of plan)
-                return fuse_deferred(m, ys, last_out, name, stage)
-            aux = [0]
             lead = {}                       # (i, j) -> (tensor, H, W) behind the chain's leading convs
             if dag:
                 # enqueue order = stream order: the leading convs of the stride-2 chains first, so
@@ -895,40 +832,11 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 for i in range(len(m.fuse_layers)):
                     for j in range(i - 1):
                         fl = m.fuse_layers[i][j]
-                        # on the lane of their SOURCE branch (free as soon as that branch is
-                        # done), or on an auxiliary stream (dag_aux: measured slower -- HIP
-                        # multiplexes streams onto 4 hardware queues, with 7 streams the lanes
-                        # serialise: 16.9 vs 13.0 ms per step, run V of round 3)
-                        if self.dag_aux:
-                            chain_lane = 4 + aux[0] % 3
-                        elif self.dag_balance:
-                            # ... or on the branch lane with the least work so far (the 56x56
-                            # branch's lane carried the heads of BOTH long chains: 4.0 of the
-                            # 4.36 ms of the stage-4 epoch, profiles/r03x_timeline_*)
-                            # (+ what the lane still has to do: its own accumulating convs)
-                            chain_lane = min(range(nb), key=lambda q: (
-                                lane_load.get(q, 0.0) + 55.0 * q + 35.0 * (nb - 1 - q), q != j))
-                        else:
-                            chain_lane = j
-                        aux[0] += 1
                         t, Ht, Wt = ys[j]
                         for k in range(i - j - 1):
                             t, Ht, Wt = conv(fl[k][0], fl[k][1], t, Ht, Wt, relu=True,
-                                             lane=chain_lane, name=f'{name}.fuse_layers.{i}.{j}.{k}')
+                                             lane=j, name=f'{name}.fuse_layers.{i}.{j}.{k}')
                         lead[(i, j)] = (t, Ht, Wt)
-            # fuse_add: the upsample terms (j > i) of an output are computed ONCE at their own
-            # resolution -- plain 1x1 convs on the lane of their source branch, enqueued here so that
-            # they run as soon as that branch is done -- and added in one pass over the output
-            # (OP_FUSEADD) instead of one upsample-scatter conv per term, each of which re-reads and
-            # re-writes the whole output from the few workgroups of a low-resolution GEMM
-            low = {}                        # (i, j) -> low-resolution term y_ij
-            if fadd:
-                for i in range(len(m.fuse_layers)):
-                    for j in range(i + 1, nb):
-                        xj, Hj, Wj = ys[j]
-                        fl = m.fuse_layers[i][j]
-                        low[(i, j)], _, _ = conv(fl[0], fl[1], xj, Hj, Wj, lane=j if dag else i,
-                                                 name=f'{name}.fuse_layers.{i}.{j}')
             outs = []
             for i in range(len(m.fuse_layers)):
                 xi, Hi_, Wi_ = ys[i]
@@ -937,14 +845,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 outb = last_out[0] if use_last else P.buf(Hi_, Wi_, xi.C)
                 o_ld = last_out[1] if use_last else xi.C
                 o_co = last_out[2] if use_last else 0
-                if fadd and i < nb - 1:
-                    # the stride-2 chains (j < i) accumulate as before, WITHOUT the final ReLU; then
-                    # out = relu(base + up(y_i,i+1) + up(y_i,i+2) + ...), base = x_i if i == 0
-                    terms = [j for j in terms if j < i]
                 for ti, j in enumerate(terms):
                     first, last = ti == 0, ti == len(terms) - 1
-                    if fadd and i < nb - 1:
-                        last = False
                     res = xi if first else outb
                     r_ld = xi.C if first else o_ld
                     r_co = 0 if first else o_co
@@ -966,17 +868,6 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                             else:
                                 t, Ht, Wt = conv(fl[k][0], fl[k][1], t, Ht, Wt, relu=True, lane=i,
                                                  name=f'{nm}.{k}')
-                if fadd and i < nb - 1:
-                    ups_terms = [low[(i, j)] for j in range(i + 1, nb)]
-                    assert 1 <= len(ups_terms) <= 3 and not use_last
-                    base = xi if not terms else outb
-                    P.op(type=_lib.OP_FUSEADD, lane=i, inb=ups_terms[0],
-                         inb2=ups_terms[1] if len(ups_terms) > 1 else None,
-                         inb3=ups_terms[2] if len(ups_terms) > 2 else None,
-                         outb=outb, resb=base, Hi=Hi_, Wi=Wi_, Cin=xi.C, in_ld=xi.C, Ho=Hi_, Wo=Wi_,
-                         Cout=xi.C, ksize=len(ups_terms), stride=1, pad=0, out_ld=o_ld, out_coff=o_co,
-                         res_ld=base.C, res_coff=0, relu=1, ups=2, tile=0, wgt_off=-1, bias_off=-1,
-                         wino_off=-1, name=f'{name}.fuse_add.{i}')
                 outs.append((outb, Hi_, Wi_))
             return outs
 
@@ -998,7 +889,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                     Hl, Wl = ys[-1][1], ys[-1][2]
                     cat = P.buf(Hl, Wl, 4 * 384)
                     last = (cat, 4 * 384, 3 * 384)
-                ys = module(m, ys, last_out=last, name=f'stage{si + 2}.{mi}', stage=si)
+                ys = module(m, ys, last_out=last, name=f'stage{si + 2}.{mi}')
             if trans is not None:
                 P.barrier()
                 nxt = []
@@ -1041,9 +932,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
     def _compile(self, H, W, device, graph=False):
         # event-driven plan: eager multi-stream forwards only (capturing it into a hipGraph segfaults
         # inside graph creation on ROCm 7.2; the captured plan keeps the barrier form)
-        # (graph == 'explicit': the event-driven plan again, as a hand-built hipGraph without any
-        # multi-stream capture -- shapy_hrnet_graph_create_explicit)
-        self._dag_eff = bool(self.dag and self.multi_stream and (not graph or graph == 'explicit'))
+        self._dag_eff = bool(self.dag and self.multi_stream and not graph)
         if self.compute_dtype not in ('f32', 'f32x6', 'bf16'):
             raise ValueError(f'unknown compute_dtype {self.compute_dtype!r}')
         bf16 = self.compute_dtype == 'bf16'
@@ -1052,10 +941,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             self._engine = {}
             self._engine_ver = ver
         key = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
-               self.wino4_min_hw, self._group_on(), self._dag_eff, self.dag_aux, self.dag_no_barriers, self.dag_balance,
-               self.wino4_n64, self.wino4_n64_min_hw, int(self.fuse_add), self.fuse_chain_lanes,
-               tuple(self.wino4_n64_cout),
-               tuple(sorted(self.layer_algo.items())),
+               self.wino4_min_hw, self._group_on(), self._dag_eff, tuple(self.wino4_n64),
+               tuple(sorted(self.wino4_ksplit.items())), tuple(sorted(self.layer_algo.items())),
                self.tile_flags, tuple(sorted(self.tile_overrides.items())))
         eng = self._engine.get(key)
         if eng is not None:
@@ -1076,19 +963,24 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             a.in_off = (-2 if o['type'] == _lib.OP_STEM else -1 if o['inb'] is None else o['inb'].off)
             a.out_off = -1 if o['outb'] is None else o['outb'].off
             a.res_off = -1 if o['resb'] is None else o['resb'].off
-            if o['type'] == _lib.OP_FUSEADD:      # the further terms travel in the weight-offset fields
-                a.wgt_off = -1 if o.get('inb2') is None else o['inb2'].off
-                a.bias_off = -1 if o.get('inb3') is None else o['inb3'].off
-                a.wino_off = -1 if o.get('inb4') is None else o['inb4'].off
+            a.split_off = -1 if o.get('scrb') is None else o['scrb'].off
+            a.cnt_off = int(o.get('cnt_off', -1))
         blob = np.frombuffer(b''.join(P.wchunks), dtype=np.uint8)
         weights = torch.from_numpy(blob.copy()).to(device)
-        eng = dict(ops=arr, n_ops=n, weights=weights, ws_per_img=ws_per_img, plan=P, ws=None,
-                   graphs={},
+        eng = dict(ops=arr, n_ops=n, weights=weights, ws_per_img=ws_per_img, cnt_per_img=P.cnt_ints,
+                   plan=P, ws=None, graphs={},
                    feat_dim=P.ops[-1]['Cin'], esz=2 if bf16 else 4,
                    dtype={'f32': _lib.DTYPE_F32, 'bf16': _lib.DTYPE_BF16,
                           'f32x6': _lib.DTYPE_F32X6}[self.compute_dtype])
         self._engine[key] = eng
         return eng
+
+    @staticmethod
+    def _counters(eng, B, device):
+        """Zeroed arrival counters of the plan's split-K layers for one workspace (None: no such layer).
+        Every completed forward leaves them zero (include/shapy_hip.h: shapy_hrnet_run)."""
+        n = eng['cnt_per_img'] * B
+        return torch.zeros(n, dtype=torch.int32, device=device) if n else None
 
     # ---- Winograd numerics guard -----------------------------------------------------------
     def calibrate(self, x, budget=None, demote=True, log=None, graph=False):
@@ -1132,8 +1024,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                     e = next(l for l in layers if l[0] == name)
                     log(f'Winograd guard: {name}: {e[1]} error {e[2]:.2e} rms-relative '
                         f'(max {e[3]:.2e}) > budget {budget:.1e} on the probe batch -> {to}')
-                    self.layer_algo[name] = to
-                    self._guard_demotions[name] = to
+                    self._guard_demote(name, to)
                 report['demoted'] = dict(self.layer_algo)
         finally:
             pass
@@ -1141,11 +1032,21 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self._calibrated_ver = self._weights_version()
         return report
 
+    def _guard_demote(self, name, to):
+        """The guard's write to layer_algo: remembers the caller's own entry for that layer, if any."""
+        prev = self._guard_demotions[name][1] if name in self._guard_demotions else self.layer_algo.get(name)
+        self._guard_demotions[name] = (to, prev)
+        self.layer_algo[name] = to
+
     def _drop_guard_demotions(self):
-        """New weights: what the guard demoted for the OLD ones is void; the caller's own entries stay."""
-        for k, v in self._guard_demotions.items():
+        """New weights: what the guard demoted for the OLD ones is void; the caller's own entries stay
+        (an entry the guard had overridden gets the caller's value back)."""
+        for k, (v, prev) in self._guard_demotions.items():
             if self.layer_algo.get(k) == v:
-                del self.layer_algo[k]
+                if prev is None:
+                    del self.layer_algo[k]
+                else:
+                    self.layer_algo[k] = prev
         self._guard_demotions = {}
 
     def _guard_probe(self, x):
@@ -1170,14 +1071,15 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         scratch_off = (eng['ws_per_img'] + 7) // 8 * 8
         biggest = max(o['Ho'] * o['Wo'] * o['ups'] ** 2 * o['Cout'] for o in P.ops if o['type'] == _lib.OP_CONV)
         ws = torch.empty((scratch_off + biggest) * B, dtype=torch.float32, device=x.device)
+        cnt = self._counters(eng, B, x.device)
         feat = torch.empty(B, eng['feat_dim'], dtype=torch.float32, device=x.device)
         one = (_lib.ShapyOp * 1)()
         out = []
 
         def run(op):
             rc = lib.shapy_hrnet_run(op, 1, _lib.ptr(eng['weights']), _lib.ptr(x), _lib.ptr(ws),
-                                     scratch_off + biggest, _lib.ptr(feat), B, H, W, 0, eng['dtype'],
-                                     _lib.current_stream())
+                                     scratch_off + biggest, _lib.ptr(cnt), eng['cnt_per_img'],
+                                     _lib.ptr(feat), B, H, W, 0, eng['dtype'], _lib.current_stream())
             _lib.check(rc, 'shapy_hrnet_run (calibration)')
         for i, o in enumerate(P.ops):
             ctypes.memmove(one, ctypes.byref(eng['ops'][i]), ctypes.sizeof(_lib.ShapyOp))
@@ -1203,13 +1105,12 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 run(one)
         return out
 
-    def _forward_graph(self, lib, eng, x, explicit=False):
+    def _forward_graph(self, lib, eng, x):
         B, _, H, W = x.shape
-        key = (B, bool(self.multi_stream), bool(explicit))
+        key = (B, bool(self.multi_stream))
         g = eng['graphs'].get(key)
         if g is None:
-            g = eng['graphs'][key] = _CapturedForward(lib, eng, B, H, W, x.device, self.multi_stream,
-                                                      explicit=explicit)
+            g = eng['graphs'][key] = _CapturedForward(lib, eng, B, H, W, x.device, self.multi_stream)
         return g(x)
 
     def forward(self, x):
@@ -1227,10 +1128,6 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             raise ValueError('HRNet input height/width must be multiples of 32')
         x = x.contiguous().float()
         use_graph = self.use_graph is True or (self.use_graph == 'auto' and B <= self.graph_max_batch)
-        if self.use_graph == 'explicit' and self.multi_stream and self.dag:
-            use_graph = 'explicit'
-        elif self.use_graph == 'explicit':
-            use_graph = True          # single-stream / barrier plans: the captured graph
         self._n_forward += 1
         if self.wino_guard and self.compute_dtype == 'f32' and self.conv_algo in ('winograd', 'winograd4', 'auto'):
             stale = self._calibrated_ver != self._weights_version()
@@ -1252,19 +1149,24 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 self.calibrate(x[:min(B, 2)], graph=use_graph)     # only ever ADDS demotions
         eng = self._compile(H, W, x.device, graph=use_graph)
         if use_graph:
-            return {'concat': self._forward_graph(lib, eng, x, explicit=use_graph == 'explicit')}
+            return {'concat': self._forward_graph(lib, eng, x)}
         need = eng['ws_per_img'] * B * eng['esz']
-        # one workspace per CALLER stream: forwards issued on different streams (several batches
-        # in flight) must not share activations
+        # one workspace (+ split-K counters) per CALLER stream: forwards issued on different streams
+        # (several batches in flight) must not share activations
         if eng['ws'] is None:
             eng['ws'] = {}
         sk = torch.cuda.current_stream().cuda_stream
-        if sk not in eng['ws'] or eng['ws'][sk].numel() < need:
-            eng['ws'][sk] = torch.empty(need, dtype=torch.uint8, device=x.device)
+        ent = eng['ws'].get(sk)
+        if ent is None or ent[0].numel() < need or ent[2] < B:
+            ent = eng['ws'][sk] = (torch.empty(need, dtype=torch.uint8, device=x.device),
+                                   self._counters(eng, B, x.device), B)
         feat = torch.empty(B, eng['feat_dim'], dtype=torch.float32, device=x.device)
         rc = lib.shapy_hrnet_run(eng['ops'], eng['n_ops'], _lib.ptr(eng['weights']), _lib.ptr(x),
-                                 _lib.ptr(eng['ws'][sk]), eng['ws_per_img'], _lib.ptr(feat), B, H, W,
-                                 int(self.multi_stream), eng['dtype'], _lib.current_stream())
+                                 _lib.ptr(ent[0]), eng['ws_per_img'], _lib.ptr(ent[1]), eng['cnt_per_img'],
+                                 _lib.ptr(feat), B, H, W, int(self.multi_stream), eng['dtype'],
+                                 _lib.current_stream())
+        if rc != 0:
+            del eng['ws'][sk]         # a failed forward may leave arrival counters behind: start clean
         _lib.check(rc, 'shapy_hrnet_run')
         return {'concat': feat}
 
@@ -1273,26 +1175,22 @@ class _CapturedForward:
     """One hipGraph of the whole backbone for a fixed batch size, with the buffers it has baked
     in (they must stay alive and in place as long as the graph exists)."""
 
-    def __init__(self, lib, eng, B, H, W, device, multi_stream, explicit=False):
+    def __init__(self, lib, eng, B, H, W, device, multi_stream):
         self.lib = lib
         self.x = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
         self.feat = torch.empty(B, eng['feat_dim'], dtype=torch.float32, device=device)
         self.ws = torch.empty(eng['ws_per_img'] * B * eng['esz'], dtype=torch.uint8, device=device)
+        self.cnt = HighResolutionNet._counters(eng, B, device)
         self.weights = eng['weights']
         self.handle = ctypes.c_void_p()
         # capture happens on a private stream inside the library; make the buffers visible to it
         torch.cuda.current_stream().synchronize()
-        if explicit:
-            rc = lib.shapy_hrnet_graph_create_explicit(
-                eng['ops'], eng['n_ops'], _lib.ptr(self.weights), _lib.ptr(self.x), _lib.ptr(self.ws),
-                eng['ws_per_img'], _lib.ptr(self.feat), B, H, W, eng['dtype'], ctypes.byref(self.handle))
-            _lib.check(rc, 'shapy_hrnet_graph_create_explicit')
-        else:
-            rc = lib.shapy_hrnet_graph_create(eng['ops'], eng['n_ops'], _lib.ptr(self.weights),
-                                              _lib.ptr(self.x), _lib.ptr(self.ws), eng['ws_per_img'],
-                                              _lib.ptr(self.feat), B, H, W, int(multi_stream),
-                                              eng['dtype'], ctypes.byref(self.handle))
-            _lib.check(rc, 'shapy_hrnet_graph_create')
+        rc = lib.shapy_hrnet_graph_create(eng['ops'], eng['n_ops'], _lib.ptr(self.weights),
+                                          _lib.ptr(self.x), _lib.ptr(self.ws), eng['ws_per_img'],
+                                          _lib.ptr(self.cnt), eng['cnt_per_img'], _lib.ptr(self.feat),
+                                          B, H, W, int(multi_stream), eng['dtype'],
+                                          ctypes.byref(self.handle))
+        _lib.check(rc, 'shapy_hrnet_graph_create')
 
     def __call__(self, x):
         self.x.copy_(x)

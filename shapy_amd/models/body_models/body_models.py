@@ -298,16 +298,20 @@ class SMPLX(VersionedWeights, nn.Module):
             ptrs[q] = None if p_ is None else dev_f32(p_, (-1, n, 3, 3)).data_ptr()
         NBpad, nb, ne = dm['NBpad'], dm['nb'], dm['ne']
         has_expr = expression is not None
-        n_arena = B * n_pose * 9 + B * NBpad * (2 if has_expr else 1)
-        arena = torch.empty(n_arena, **f32)
-        full_pose = arena[:B * n_pose * 9].view(B, n_pose, 3, 3)
-        o = B * n_pose * 9
-        coeffs = arena[o:o + B * NBpad].view(B, NBpad)
-        coeffs_shape = arena[o + B * NBpad:].view(B, NBpad) if has_expr else None
-        betas_t = None if betas is None else dev_f32(betas, (B, -1))
+        # one arena: the coefficient rows FIRST -- they are the A operand of the blend-shape GEMMs, whose
+        # kernel wants 16-byte-aligned inputs (conv_prepare), and B * NBpad is a multiple of 4 floats; the
+        # pose slice behind them starts aligned too and nothing needs to follow it
+        n_co = B * NBpad * (2 if has_expr else 1)
+        assert NBpad % 4 == 0
+        arena = torch.empty(n_co + B * n_pose * 9, **f32)
+        coeffs = arena[:B * NBpad].view(B, NBpad)
+        coeffs_shape = arena[B * NBpad:n_co].view(B, NBpad) if has_expr else None
+        full_pose = arena[n_co:].view(B, n_pose, 3, 3)
+        # (reshape by the tensor's OWN batch: a [1, nb] row broadcasts to B in dev_f32)
+        betas_t = None if betas is None else dev_f32(betas, (betas.shape[0], -1))
         if betas_t is not None and betas_t.shape[1] != nb:
             raise ValueError(f'betas: expected {nb} coefficients, got {betas_t.shape[1]}')
-        expr_t = dev_f32(expression, (B, -1)) if has_expr else None
+        expr_t = dev_f32(expression, (expression.shape[0], -1)) if has_expr else None
         if has_expr and expr_t.shape[1] != ne:
             raise ValueError(f'expression: expected {ne} coefficients, got {expr_t.shape[1]}')
         _lib.check(lib.shapy_smplx_prepare_f32(

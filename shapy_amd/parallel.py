@@ -51,24 +51,29 @@ class BetasGatherer:
     def __init__(self, world=None, group=None, force=False, mode=None):
         """force: take the collective path even for ONE rank (bench.py --force-gather: a world-size-1
         RCCL group exercises the stream / event structure of the N-rank path on a single GPU).
-        mode: 'rccl' (default) = ncclAllGather called directly on the CALLER's stream
-        (shapy_amd/rccl.py): no extra stream at all -- measured on one GPU with a world-size-1
-        group, c10d's own RCCL stream alone cost the four-lane backbone 17 % (4,140-4,170 vs 5,020
-        images/s, profiles/r04j_*: HIP multiplexes a process's streams onto a few hardware queues);
-        'work' = c10d, async_op=True from the caller's stream, the Work handle joined (a stream-side
-        wait) at the next call; 'side' = rounds 1-3: c10d on a private side stream.  'work' / 'side'
-        defer the join by one step; with 'rccl' the result is simply next in stream order.
+        mode: 'lane' (default) = ncclAllGather called directly (shapy_amd/rccl.py) on the executor's
+        lane-1 stream -- a stream the process already has (c10d's own RCCL stream alone cost the
+        four-lane backbone 17 % on one GPU, 4,140-4,170 vs 5,020 images/s, profiles/r04j_*: HIP
+        multiplexes a process's streams onto a few hardware queues) -- behind an event recorded on the
+        caller's stream once the betas exist, and joined back into the caller's stream by the NEXT
+        call.  The compute stream never queues behind the collective, i.e. never behind the slowest
+        rank: lane 1 gets its first op of the next forward ~1.4 ms into it (transition1), by which
+        time the latency-bound gather has long finished.
+        'rccl' = round 4: the same direct call on the CALLER's stream (every rank's next step queues
+        behind the collective); 'work' = c10d, async_op=True from the caller's stream, the Work handle
+        joined at the next call; 'side' = rounds 1-3: c10d on a private side stream.
         SHAPY_GATHER_MODE overrides the default."""
         import os
         self.group = group
         self.world = world if world is not None else (
             dist.get_world_size(group) if dist.is_initialized() else 1)
         self.force = bool(force)
-        self.mode = mode or os.environ.get('SHAPY_GATHER_MODE', 'rccl')
-        if self.mode not in ('rccl', 'work', 'side'):
+        self.mode = mode or os.environ.get('SHAPY_GATHER_MODE', 'lane')
+        if self.mode not in ('lane', 'rccl', 'work', 'side'):
             raise ValueError(f'unknown gather mode {self.mode!r}')
-        self._comm = None             # mode 'rccl': shapy_amd.rccl.RcclComm, created on first use
+        self._comm = None             # modes 'lane' / 'rccl': shapy_amd.rccl.RcclComm, created on first use
         self._stream = None
+        self._lane = None             # mode 'lane': the executor's lane-1 stream (torch.cuda.ExternalStream)
         self._pending = None          # (out, event | Work | None) of the gather still in flight
         self.issued = 0
         self.deferred_waits = 0       # waits that were served by a LATER call (the overlap)
@@ -96,13 +101,23 @@ class BetasGatherer:
         local = local.contiguous()
         out = local.new_empty((self.world * local.shape[0],) + tuple(local.shape[1:]))
         self.issued += 1
-        if local.is_cuda and self.mode == 'rccl':
-            # RCCL called directly on the CALLER's stream (shapy_amd/rccl.py): no stream of its own,
-            # no event -- the gather is one more kernel behind the step's tail
+        if local.is_cuda and self.mode in ('lane', 'rccl'):
             if self._comm is None and not self._init_rccl():
                 return self._call_c10d(local, out)          # every rank fell back to mode 'work'
-            out = self._comm.all_gather(local)
-            self._pending = (out, None, local)
+            if self.mode == 'rccl':
+                # on the CALLER's stream: no event -- the gather is one more kernel behind the step's tail
+                out = self._comm.all_gather(local, out=out)
+                self._pending = (out, None, local)
+            else:
+                # on the executor's lane-1 stream, behind the producer of `local`; joined by the next call
+                lane = self._lane_stream(local.device)
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(local.device))
+                lane.wait_event(ready)
+                self._comm.all_gather(local, stream=lane.cuda_stream, out=out)
+                done = torch.cuda.Event()
+                done.record(lane)
+                self._pending = (out, done, local)     # `local` / `out` stay referenced until the join
         elif local.is_cuda and self.mode == 'work':
             work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
             self._pending = (out, work, local)       # `local` stays referenced until the join
@@ -123,6 +138,25 @@ class BetasGatherer:
             self._pending = (out, None)
         return out
 
+    def _lane_stream(self, device):
+        if self._lane is None:
+            import ctypes
+            from . import _lib
+            h = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(_lib.load().shapy_hrnet_lane_stream(1, ctypes.byref(h)), 'shapy_hrnet_lane_stream')
+            self._lane = torch.cuda.ExternalStream(h.value, device=device)
+        return self._lane
+
+    def _agree(self, ok):
+        """min over the ranks of an ok flag (control plane); one rank: the flag itself."""
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dev = 'cuda' if dist.get_backend(self.group) == 'nccl' else 'cpu'
+            flag = torch.tensor([int(ok)], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return int(flag.item())
+        return int(ok)
+
     def _init_rccl(self):
         """Creates the direct RCCL communicator on first use.  Returns False when ANY rank could not
         (agreed over the control plane, so that all ranks take the same path): the gatherer then
@@ -131,21 +165,30 @@ class BetasGatherer:
         import logging
         import os
         from .rccl import RcclComm
+        # Two phases, each followed by an agreement over the control plane, so that NO rank enters a
+        # collective of the communicator's construction unless every rank will: (1) local -- load
+        # librccl, the group's rank 0 draws the unique id; (2) collective -- id broadcast + the blocking
+        # ncclCommInitRank.  A rank that fails in (1) (librccl missing, ncclGetUniqueId error, the test
+        # hook on a subset of ranks) makes everybody skip (2) and take the c10d fallback together.
         ok, err = 1, None
         try:
-            if os.environ.get('SHAPY_RCCL_FORCE_FAIL') == '1':
-                raise RuntimeError('SHAPY_RCCL_FORCE_FAIL=1 (test hook)')
-            self._comm = RcclComm(world=self.world if not dist.is_initialized() else None,
-                                  group=self.group)
+            force = os.environ.get('SHAPY_RCCL_FORCE_FAIL', '')
+            if force == '1' or (force.startswith('rank') and dist.is_initialized()
+                                and dist.get_rank(self.group) == int(force[4:])):
+                raise RuntimeError(f'SHAPY_RCCL_FORCE_FAIL={force} (test hook)')
+            self._comm = RcclComm.prepare(world=self.world if not dist.is_initialized() else None,
+                                          group=self.group)
             if self._comm.world != self.world:
                 raise RuntimeError(f'BetasGatherer(world={self.world}) on a group of {self._comm.world}')
         except Exception as e:                 # noqa: BLE001 -- any failure means "fall back"
             ok, err = 0, e
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dev = 'cuda' if dist.get_backend(self.group) == 'nccl' else 'cpu'
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-            ok = int(flag.item())
+        ok = self._agree(ok)
+        if ok:
+            try:
+                self._comm.connect()
+            except Exception as e:             # noqa: BLE001
+                ok, err = 0, e
+            ok = self._agree(ok)
         if ok:
             return True
         if self._comm is not None:
@@ -158,8 +201,12 @@ class BetasGatherer:
             raise RuntimeError('no RCCL communicator and no process group to fall back to') from err
         self.mode = 'work'
         if dist.get_backend(self.group) != 'nccl':
-            self.group = dist.new_group(backend='nccl')          # collective: every rank is here
+            self.group = self._fallback_group()                  # collective: every rank is here
         return False
+
+    def _fallback_group(self):
+        ranks = None if self.group is None else dist.get_process_group_ranks(self.group)
+        return dist.new_group(ranks=ranks, backend='nccl')
 
     def _call_c10d(self, local, out):
         work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)

@@ -33,7 +33,7 @@ def lib():
 
 
 def _conv_call(lib, x, w, b, res=None, relu=False, stride=1, pad=0, ups=1, tile=0, out=None,
-               out_ld=None, out_coff=0, x6=False, wino=False):
+               out_ld=None, out_coff=0, x6=False, wino=False, ksplit=1, split_bufs=None):
     """x [B,H,W,C] NHWC cuda, w [O,kh,kw,C] cuda -> out NHWC."""
     from shapy_amd import _lib
     B, Hi, Wi, C = x.shape
@@ -63,6 +63,13 @@ def _conv_call(lib, x, w, b, res=None, relu=False, stride=1, pad=0, ups=1, tile=
         wu = torch.from_numpy(winograd.transform_filters4(w.cpu().numpy())).to(x.device)
         d.wgt_wino = wu.data_ptr()
         d.tile = tile | _lib.TILE_WINO4
+        if ksplit > 1:                                 # split-K: slab + zeroed counters from the caller
+            slab, ncnt = _lib.w4_split_sizes(Hi, Wi, O, ksplit)
+            if split_bufs is None:
+                split_bufs = (torch.full((slab * B,), float('nan'), device=x.device),
+                              torch.zeros(ncnt * B, dtype=torch.int32, device=x.device))
+            d.split_ws, d.split_cnt = split_bufs[0].data_ptr(), split_bufs[1].data_ptr()
+            d.tile |= _lib.tile_w4_ksplit(ksplit)
     elif wino:                                         # Winograd-transformed filters as well
         from shapy_amd.utils import winograd
         wu = torch.from_numpy(winograd.transform_filters(w.cpu().numpy())).to(x.device)
@@ -212,28 +219,84 @@ WINO4_CASES = [
 ]
 
 
-# tile flag 0x400000 (A/B knob added after round 4's GPU budget was spent): the 64-channel N tile on widths
-# that are multiples of 48 too -- same kernel instantiations as the Cout = 64 / 128 / 512 cases above, new
-# shapes; non-strict xfail until their first run
-WINO4_N64_FORCED = [(1, 14, 14, 192, 192, True, True), (1, 7, 7, 384, 384, True, True),
-                    (2, 28, 28, 96, 192, False, True)]
+# split-K (csrc/conv_wino4.hip, template parameter S): B, H, W, Cin, Cout, res, relu, S
+WINO4_SPLIT_CASES = [
+    (64, 7, 7, 384, 384, True, True, 2),       # the 7x7 branch at the headline batch: 256 workgroups, KC = 12
+    (64, 7, 7, 384, 384, True, True, 3),       # 8 chunks per slice
+    (64, 7, 7, 384, 384, False, True, 4),      # 6 chunks per slice, four-term ordered sum
+    (1, 7, 7, 384, 384, True, True, 2),        # 4 of 16 tiles live (dead lanes never touch the slab)
+    (3, 7, 9, 96, 96, True, False, 2),         # partial edge tiles, generic chunk loop (3 chunks per slice)
+    (64, 14, 14, 192, 192, True, True, 2),     # the 14x14 branch: KC = 6
+    (5, 7, 7, 512, 512, False, True, 2),       # 64-channel N tile (four multiplying waves), 16 chunks per slice
+    (5, 7, 7, 512, 512, True, True, 4),
+]
 
 
-@pytest.mark.xfail(strict=False, reason='A/B knob written after the GPU budget of round 4 was spent: first run')
-@pytest.mark.parametrize('case', WINO4_N64_FORCED, ids=[str(c) for c in WINO4_N64_FORCED])
-def test_conv_winograd4_forced_64_channel_tile_vs_float64(lib, case):
-    from shapy_amd import _lib
-    B, H, W, Cin, Cout, use_res, relu = case
+@pytest.mark.parametrize('case', WINO4_SPLIT_CASES, ids=[str(c) for c in WINO4_SPLIT_CASES])
+def test_conv_winograd4_split_k_vs_float64(lib, case):
+    """F(4x4) with the K loop cut into S slices on S workgroups per output tile: against float64 and
+    against the unsplit kernel (same products, the S partial sums added in slice order: float32
+    rounding apart), REPEATED on the same slab / counters -- the kernel leaves its arrival counters
+    zero, the result is bit-identical from launch to launch whichever slice arrives last -- and with
+    a busy stream in front so that slices of a tile start at different times."""
+    B, H, W, Cin, Cout, use_res, relu, S = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     x = torch.randn(B, H, W, Cin, generator=g).cuda()
     w = (torch.randn(Cout, 3, 3, Cin, generator=g) / np.sqrt(9 * Cin)).cuda()
     b = torch.randn(Cout, generator=g).cuda()
     res = torch.randn(B, H, W, Cout, generator=g).cuda() if use_res else None
-    out = _conv_call(lib, x, w, b, res, relu, 1, 1, wino=4, tile=_lib.TILE_WINO4_N64)
+    from shapy_amd import _lib
+    slab, ncnt = _lib.w4_split_sizes(H, W, Cout, S)
+    bufs = (torch.full((slab * B,), float('nan'), device='cuda'),
+            torch.zeros(ncnt * B, dtype=torch.int32, device='cuda'))
     base = _conv_call(lib, x, w, b, res, relu, 1, 1, wino=4)
     ref = _conv_ref(x, w, b, res, relu, 1, 1)
-    assert (out.cpu().double() - ref).abs().max().item() < 2e-6 * np.sqrt(9 * Cin)
-    assert torch.equal(out, base)          # same products in the same order, another workgroup shape
+    tol = 2e-6 * np.sqrt(9 * Cin)
+    assert (base.cpu().double() - ref).abs().max().item() < tol
+    outs = []
+    for rep in range(6):
+        if rep % 2:                     # uneven load: another kernel still running when the slices start
+            junk = torch.randn(4096, 4096, device='cuda')
+            junk = junk @ junk
+        outs.append(_conv_call(lib, x, w, b, res, relu, 1, 1, wino=4, ksplit=S, split_bufs=bufs).clone())
+        assert int(bufs[1].abs().sum().item()) == 0, 'arrival counters not back to zero'
+    e = (outs[0].cpu().double() - ref).abs()
+    d = (outs[0] - base).abs().max().item()
+    print(f'split-K S={S}: max err vs float64 {e.max().item():.3e} (tol {tol:.1e}), vs the unsplit kernel {d:.3e}, '
+          f'NaNs {int(torch.isnan(outs[0]).sum())}, launches equal {[bool(torch.equal(o, outs[0])) for o in outs[1:]]}')
+    assert e.max().item() < tol, (e.max().item(), (e > tol).float().mean().item())
+    assert d < tol                        # another association of the same float32 sums
+    assert all(torch.equal(o, outs[0]) for o in outs[1:]), 'split-K result changes from launch to launch'
+
+
+def test_conv_winograd4_split_k_refusals(lib):
+    """No slab / counters, a slice count that does not divide the chunks, S on a non-F(4x4) layer."""
+    from shapy_amd import _lib
+    x = torch.randn(1, 7, 7, 96).cuda()
+    w = torch.randn(96, 3, 3, 96).cuda()
+    out = torch.full((1, 7, 7, 96), 7.0).cuda()
+    from shapy_amd.utils import winograd
+    wu = torch.from_numpy(winograd.transform_filters4(w.cpu().numpy())).cuda()
+    slab, ncnt = _lib.w4_split_sizes(7, 7, 96, 4)
+    ws, cnt = torch.zeros(slab).cuda(), torch.zeros(ncnt, dtype=torch.int32).cuda()
+
+    def call(S, with_bufs):
+        d = _lib.ShapyConv()
+        d.dtype = _lib.DTYPE_F32
+        d.in_, d.wgt, d.out, d.wgt_wino = x.data_ptr(), w.data_ptr(), out.data_ptr(), wu.data_ptr()
+        d.B, d.Hi, d.Wi, d.Cin, d.in_ld, d.Ho, d.Wo, d.Cout = 1, 7, 7, 96, 96, 7, 7, 96
+        d.ksize, d.stride, d.pad, d.out_ld, d.ups = 3, 1, 1, 96, 1
+        d.tile = _lib.TILE_WINO4 | _lib.tile_w4_ksplit(S)
+        if with_bufs:
+            d.split_ws, d.split_cnt = ws.data_ptr(), cnt.data_ptr()
+        return lib.shapy_conv2d(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert call(2, False) == -1          # SHAPY_EINVAL: no slab
+    assert call(4, True) == -1           # 6 chunks do not split four ways
+    torch.cuda.synchronize()
+    assert torch.equal(out, torch.full_like(out, 7.0))      # nothing was launched
+    assert call(2, True) == 0
+    torch.cuda.synchronize()
+    assert not torch.equal(out, torch.full_like(out, 7.0)) and int(cnt.abs().sum()) == 0
 
 
 @pytest.mark.parametrize('case', WINO4_CASES, ids=[str(c) for c in WINO4_CASES])
@@ -743,32 +806,6 @@ def test_hrnet_two_host_threads_on_two_streams_bit_identical(network):
         assert all(torch.equal(g, refs[i]) for g in outs[i])
 
 
-def test_hrnet_explicit_graph_of_the_event_driven_plan_equals_eager(network):
-    """use_graph = 'explicit': the event-driven plan as a hand-built hipGraph (kernel nodes read back
-    from a single-stream capture, edges = lane order + sig / wait slots + barrier joins; no multi-stream
-    capture) replays bit-identically to the eager four-stream forward of the SAME plan, several
-    replays in a row, at two batch sizes."""
-    from shapy_amd.models.backbone import hrnet as hrnet_mod
-    from shapy_amd.utils import synthetic as syn
-    bb = network.backbone
-    keep = bb.multi_stream, bb.use_graph, bb.dag
-    bb.multi_stream, bb.dag, bb.conv_algo = True, True, hrnet_mod.DEFAULT_CONV_ALGO
-    try:
-        for B, size in ((1, 224), (3, 96)):
-            x = torch.from_numpy(syn.synthetic_images(B, size, 31)).cuda()
-            bb.use_graph = False
-            with torch.no_grad():
-                ref = bb(x)['concat'].clone()
-            bb.use_graph = 'explicit'
-            with torch.no_grad():
-                got = [bb(x)['concat'].clone() for _ in range(3)]
-            torch.cuda.synchronize()
-            assert all(torch.equal(g, ref) for g in got), (B, size)
-    finally:
-        bb.multi_stream, bb.use_graph, bb.dag = keep
-        bb.conv_algo = 'direct'
-
-
 def test_conv2d_group_c_abi_matches_single_launches():
     """shapy_conv2d_group through the C-ABI: groups of 1-4 layers incl. partly filled workgroups,
     a channel-offset epilogue, Cout = 144 (the generic XCD split), more tasks than workgroup slots;
@@ -954,6 +991,42 @@ def test_smplx_ops_vs_reference_golden(network, golden_dir):
     scale = torch.nn.functional.softplus(cam[:, :1])
     proj = network.projection(so['joints'], scale=scale, translation=cam[:, 1:3])
     assert np.abs(proj._t.cpu().numpy() - g['cam_proj']).max() < 1e-4
+
+
+@pytest.mark.parametrize('B', [1, 3, 4])
+def test_smplx_forward_odd_batches_and_full_pose_vs_oracle(network, B):
+    """SMPLX.forward through its generic argument path (not the regressor's fast head) at batch sizes
+    whose pose block is not a multiple of 16 bytes: global_rot + body_pose (22 joints: B * 198 floats) and
+    all 55 joints given explicitly (identity jaw / eyes / hands) -- the coefficient rows are the GEMM's A
+    operand and must stay 16-byte aligned whatever B is.  Also a [1, 10] betas row broadcast to B."""
+    from oracle import body_np
+    from shapy_amd.utils import synthetic as syn
+    model = syn.make_synthetic_smplx(0)
+    rng = np.random.default_rng(40 + B)
+    rot = body_np.cont_rot_repr_decode(rng.standard_normal((B, 22, 6)).astype(np.float32) * 0.5 +
+                                       np.array([1, 0, 0, 1, 0, 0], np.float32)).astype(np.float32)
+    betas = (rng.standard_normal((B, 10)) * 1.5).astype(np.float32)
+    ref = body_np.smplx_forward(model, rot[:, :1], rot[:, 1:], betas)
+    r = torch.from_numpy(rot).cuda()
+    bt = torch.from_numpy(betas).cuda()
+
+    def eye(n):
+        return torch.eye(3, device='cuda').view(1, 1, 3, 3).expand(B, n, 3, 3).contiguous()
+    with torch.no_grad():
+        a = network.model(global_rot=r[:, :1], body_pose=r[:, 1:], betas=bt, get_skin=True, return_shaped=True)
+        b = network.model(global_rot=r[:, :1], body_pose=r[:, 1:], jaw_pose=eye(1), leye_pose=eye(1),
+                          reye_pose=eye(1), left_hand_pose=eye(15), right_hand_pose=eye(15), betas=bt,
+                          get_skin=True, return_shaped=True, return_full_pose=True)
+        c = network.model(global_rot=r[:, :1], body_pose=r[:, 1:], betas=bt[:1], get_skin=True)
+    torch.cuda.synchronize()
+    for out in (a, b):
+        assert np.abs(out['vertices'].cpu().numpy() - ref['vertices']).max() < 1e-4
+        assert np.abs(out['joints']._t.cpu().numpy() - ref['joints']).max() < 1e-4
+        assert np.abs(out['v_shaped'].cpu().numpy() - ref['v_shaped']).max() < 1e-5
+    assert torch.equal(a['vertices'], b['vertices'])
+    assert np.abs(b['full_pose'].cpu().numpy() - ref['full_pose']).max() < 1e-6
+    ref1 = body_np.smplx_forward(model, rot[:, :1], rot[:, 1:], np.repeat(betas[:1], B, 0))
+    assert np.abs(c['vertices'].cpu().numpy() - ref1['vertices']).max() < 1e-4
 
 
 def test_shipped_sample_pins(network, golden_dir):
@@ -1337,7 +1410,7 @@ def _nccl_one_rank_worker(port, q):
     dist.init_process_group('nccl', init_method='env://')
     try:
         ok = {}
-        for mode in ('rccl', 'work', 'side'):
+        for mode in ('lane', 'rccl', 'work', 'side'):
             gat = parallel.BetasGatherer(1, force=True, mode=mode)
             side = torch.cuda.Stream()
             with torch.cuda.stream(side):              # a non-default caller stream, as in serving
@@ -1363,9 +1436,10 @@ def _nccl_one_rank_worker(port, q):
 
 def test_rccl_forced_gather_one_rank_both_modes():
     """bench.py --force-gather's path: a world-size-1 RCCL group on ONE GPU runs the collective of the
-    N-rank path in all three issue modes of BetasGatherer ('rccl', the default: ncclAllGather called
-    directly on the caller's stream, shapy_amd/rccl.py; 'work': c10d async collective from the
-    caller's stream; 'side': c10d on a private side stream)."""
+    N-rank path in all four issue modes of BetasGatherer ('lane', the default: ncclAllGather called
+    directly on the executor's lane-1 stream and joined one step later, shapy_amd/rccl.py; 'rccl': the
+    same call on the caller's stream; 'work': c10d async collective from the caller's stream; 'side':
+    c10d on a private side stream)."""
     _need_gpu()
     import socket
     import torch.multiprocessing as mp
@@ -1378,7 +1452,7 @@ def test_rccl_forced_gather_one_rank_both_modes():
     p.start()
     res = q.get(timeout=300)
     p.join(timeout=60)
-    assert res == {'rccl': True, 'work': True, 'side': True, 'fallback': True}, res
+    assert res == {'lane': True, 'rccl': True, 'work': True, 'side': True, 'fallback': True}, res
 
 
 def test_rccl_allgather_two_ranks():

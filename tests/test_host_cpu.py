@@ -55,7 +55,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.shapy_abi_version() == 7
+    assert lib.shapy_abi_version() == 8
     assert lib.shapy_build_arch() == b'gfx950'
     # struct layouts agree with the C header (sizeof through a tiny C program)
     src = '#include <stdio.h>\n#include "shapy_hip.h"\nint main(){printf("%zu %zu %zu", ' \
@@ -139,50 +139,40 @@ def _executor_order(ops):
     return reach
 
 
-@pytest.mark.parametrize('dag,group,aux', [(True, False, False), (True, False, True), (True, False, 'nobar'),
-                                           (False, False, False), (False, True, False),
-                                           (True, False, 'fuse_add'), (False, False, 'fuse_add'),
-                                           (False, True, 'fuse_add'),
-                                           (True, False, 'fuse_add2:dest,dest,mixed'),
-                                           (True, False, 'fuse_add2:source,source,source'),
-                                           (True, False, 'fuse_add2:dest,dest,dest'),
-                                           (False, False, 'fuse_add2:dest,dest,mixed'),
-                                           (False, True, 'fuse_add2:dest,dest,mixed')])
-def test_plan_orders_every_memory_hazard(hrnet, dag, group, aux):
+@pytest.mark.parametrize('dag,group,ksplit', [(True, False, {}), (True, False, {(384, 4): 2}),
+                                              (True, False, {(384, 4): 4, (192, 16): 2}),
+                                              (False, False, {(384, 4): 2}), (False, True, {(384, 4): 2})])
+def test_plan_orders_every_memory_hazard(hrnet, dag, group, ksplit):
     """The executor's order (lanes, barriers, dependency events, launch groups) covers every hazard
     of the PACKED workspace: whenever two ops touch overlapping memory and at least one of them
     writes, one of them has finished before the other starts.  Checked for the event-driven plan
-    (dag), the round-2 barrier plan and the grouped single-stream plan."""
-    keep = hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw
+    (dag), the round-2 barrier plan and the grouped single-stream plan, with and without split-K
+    layers (whose slabs are buffers of the same workspace)."""
+    from shapy_amd import _lib
+    keep = hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw, hrnet.wino4_ksplit
     try:
         hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw = dag, group, 'winograd4', 7
-        hrnet.dag_aux, hrnet.dag_no_barriers = aux is True, aux == 'nobar'
-        hrnet.fuse_add = 1 if aux == 'fuse_add' else 2 if str(aux).startswith('fuse_add2') else 0
-        keep_lanes = hrnet.fuse_chain_lanes
-        if hrnet.fuse_add == 2:
-            hrnet.fuse_chain_lanes = aux.split(':')[1]
+        hrnet.wino4_ksplit = ksplit
         P = hrnet._build_plan(224, 224)
         waits = P.sync_plan()
         total = P.allocate()
     finally:
-        hrnet.dag_aux = hrnet.dag_no_barriers = False
-        hrnet.fuse_add = 0
-        hrnet.fuse_chain_lanes = keep_lanes
-        hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw = keep
-    if str(aux).startswith('fuse_add'):
-        assert sum(1 for o in P.ops if o['type'] == 3) == (18 if aux == 'fuse_add' else 26)
-        assert not any(o['ups'] > 1 for o in P.ops if o['type'] == 0)
+        hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw, hrnet.wino4_ksplit = keep
+    n_split = sum(1 for o in P.ops if o.get('scrb') is not None)
+    # 384 -> 384 @7x7: 3 modules x 8 convs, 192 -> 192 @14x14: 7 modules x 8; none inside launch groups
+    assert n_split == (0 if not ksplit else 0 if group else 24 + (56 if (192, 16) in ksplit else 0))
+    cnts = sorted((o['cnt_off'], _lib.w4_split_sizes(o['Hi'], o['Wi'], o['Cout'], 2)[1])
+                  for o in P.ops if o.get('scrb') is not None)
+    assert all(c0 + n <= c1 for (c0, n), (c1, _) in zip(cnts, cnts[1:]))      # disjoint counter slices
+    assert not cnts or cnts[-1][0] + cnts[-1][1] == P.cnt_ints
     ops = P.ops
     reach = _executor_order(ops)
     if dag:
         assert sum(1 for w in waits if w) > 30 and sum(o['barrier_before'] for o in ops) < 20
-    if aux == 'nobar':
-        assert sum(o['barrier_before'] for o in ops) == 0
     # memory accesses: (op, write?, first float, end float, channel window inside a pixel row)
     acc = []
     for i, o in enumerate(ops):
-        for key, is_w, c0, cn in (('inb', False, 0, None), ('inb2', False, 0, None), ('inb3', False, 0, None),
-                                  ('inb4', False, 0, None),
+        for key, is_w, c0, cn in (('inb', False, 0, None), ('scrb', True, 0, None),
                                   ('resb', False, o['res_coff'], o['Cout']),
                                   ('outb', True, o['out_coff'], o['Cout'])):
             b = o.get(key)
@@ -209,27 +199,25 @@ def test_plan_orders_every_memory_hazard(hrnet, dag, group, aux):
     assert total * 4 / 1e6 < 20.0            # MB per 224x224 image: packing works (no reuse: 112 MB)
 
 
-@pytest.mark.parametrize('size,fuse_add', [(64, 0), (256, 0), (64, 1), (256, 1), (64, 2), (256, 2)])
-def test_event_driven_plan_at_other_input_sizes(hrnet, size, fuse_add):
+@pytest.mark.parametrize('size', [64, 256])
+def test_event_driven_plan_at_other_input_sizes(hrnet, size):
     """The dependency events fit their 64 slots and at most three waits per op at the sizes the
     reference uses besides 224 (256: expose configs; 64: the smallest legal input), and the
     executor's order still covers every hazard of the packed workspace."""
     keep = hrnet._dag_eff, hrnet.conv_algo
     try:
-        hrnet._dag_eff, hrnet.conv_algo, hrnet.fuse_add = True, 'winograd4', fuse_add
+        hrnet._dag_eff, hrnet.conv_algo = True, 'winograd4'
         P = hrnet._build_plan(size, size)
         waits = P.sync_plan()
         total = P.allocate()
     finally:
         hrnet._dag_eff, hrnet.conv_algo = keep
-        hrnet.fuse_add = 0
     ops = P.ops
     assert max(len(w) for w in waits) <= 3 and max(o['sig'] for o in ops) < 64
     reach = _executor_order(ops)
     spans = []
     for i, o in enumerate(ops):
-        for key, is_w in (('inb', False), ('inb2', False), ('inb3', False), ('inb4', False), ('resb', False),
-                          ('outb', True)):
+        for key, is_w in (('inb', False), ('scrb', True), ('resb', False), ('outb', True)):
             b = o.get(key)
             if b is not None:
                 spans.append((i, is_w, b.off, b.off + b.size, id(b)))
@@ -384,12 +372,12 @@ def test_winograd4_plan_filters_and_kernel_indexing(hrnet):
     w4 = [o for o in P.ops if o['type'] == 0 and o['tile'] & _lib.TILE_WINO4]
     assert all(min(o['Hi'], o['Wi']) >= hrnet.wino4_min_hw and o['Cout'] % 48 == 0 and
                o['wino_off'] >= 0 for o in w4)
-    # the 64-channel N tile (opt-in): layer1's four 64 -> 64 @56x56 convs join, the 7x7 head convs do not
-    hrnet.conv_algo, hrnet.wino4_n64 = 'winograd4', True
+    # the 64-channel N tile (opt-in per output width): layer1's four 64 -> 64 @56x56 convs join
+    hrnet.conv_algo, hrnet.wino4_n64 = 'winograd4', (64,)
     try:
         P64 = hrnet._build_plan(224, 224)
     finally:
-        hrnet.conv_algo, hrnet.wino4_n64 = 'winograd', False
+        hrnet.conv_algo, hrnet.wino4_n64 = 'winograd', ()
     assert count(P64) == (189, 29)
     assert sorted(o['name'] for o in P64.ops if o['type'] == 0 and o['tile'] & _lib.TILE_WINO4
                   and o['Cout'] % 48) == [f'layer1.{i}.conv2' for i in range(4)]
@@ -415,18 +403,28 @@ def test_winograd4_plan_filters_and_kernel_indexing(hrnet):
     emu.check(1, 14, 14, 16, 48, False, False, coff=16)  # channel-offset epilogue
 
 
-def test_forced_64_channel_tile_flag_marks_the_192_and_384_channel_layers(hrnet):
+def test_split_k_policy_marks_the_7x7_branch_and_nothing_else(hrnet):
+    """Default plan: the 24 convs of the 384-channel branch on the 7x7 maps carry SHAPY_TILE_W4_KSPLIT(2),
+    a slab of 2 x 4 tiles x 16 pixels x 384 channels per image and 48 counters per image each; the choice
+    does not depend on the batch (the plan has no batch) and is the same at 256 x 256 (8x8 maps: 4 tiles)."""
     from shapy_amd import _lib
-    keep = hrnet.conv_algo, hrnet.wino4_n64_cout
+    from shapy_amd.models.backbone.hrnet import DEFAULT_WINO4_KSPLIT
+    keep = hrnet.conv_algo, hrnet.wino4_ksplit
     try:
-        hrnet.conv_algo, hrnet.wino4_n64_cout = 'winograd4', (192, 384)
-        P = hrnet._build_plan(224, 224)
+        hrnet.conv_algo, hrnet.wino4_ksplit = 'winograd4', dict(DEFAULT_WINO4_KSPLIT)
+        plans = {size: hrnet._build_plan(size, size) for size in (224, 256)}
     finally:
-        hrnet.conv_algo, hrnet.wino4_n64_cout = keep
-    w4 = [o for o in P.ops if o['type'] == 0 and o['tile'] & _lib.TILE_WINO4]
-    flagged = [o for o in w4 if o['tile'] & _lib.TILE_WINO4_N64]
-    assert len(w4) == 209 and {o['Cout'] for o in flagged} == {192, 384}
-    assert len(flagged) == sum(1 for o in w4 if o['Cout'] in (192, 384)) == 80
+        hrnet.conv_algo, hrnet.wino4_ksplit = keep
+    for size, P in plans.items():
+        split = [o for o in P.ops if o['type'] == 0 and (o['tile'] >> 21) & 3]
+        assert len(split) == 24 and {(o['Cin'], o['Cout'], o['Hi']) for o in split} == {(384, 384, size // 32)}
+        assert all((o['tile'] >> 21) & 3 == 1 and o['tile'] & _lib.TILE_WINO4 for o in split)
+        assert all(o['scrb'].size == 2 * 4 * 16 * 384 for o in split)
+        assert P.cnt_ints == 24 * 2 * 24
+    assert _lib.w4_split_sizes(7, 7, 384, 2) == (2 * 4 * 16 * 384, 48)
+    assert _lib.w4_split_sizes(14, 14, 192, 2) == (2 * 16 * 16 * 192, 24)
+    with pytest.raises(ValueError):
+        _lib.tile_w4_ksplit(5)
 
 
 def test_bench_flop_accounting_algorithmic_vs_executed(hrnet):
@@ -518,6 +516,79 @@ def _dp_worker(rank, world, port, q):
            and torch.equal(gat.gather(full[r * 3:(r + 1) * 3]), full[:6]))
     q.put((rank, ok1, ok2, (a, b)))
     dist.destroy_process_group()
+
+
+class _FakeRccl:
+    """librccl stand-in for the CPU: records what the construction of a communicator asks of it."""
+
+    def __init__(self, rank):
+        self.rank, self.calls = rank, []
+
+    def ncclGetUniqueId(self, uid_ref):
+        import ctypes
+        ctypes.memmove(uid_ref, bytes(range(100, 228)), 128)
+        self.calls.append('id')
+        return 0
+
+    def ncclCommInitRank(self, comm_ref, world, uid, rank):
+        self.calls.append(('init', world, rank, bytes(uid.internal)))
+        return 0
+
+    def ncclCommDestroy(self, comm):
+        return 0
+
+    def ncclGetErrorString(self, rc):
+        return b'fake'
+
+
+def _rccl_init_worker(rank, world, port, q, force):
+    """BetasGatherer._init_rccl on gloo ranks with librccl stubbed: (a) every rank healthy -> the id
+    drawn on rank 0 reaches every rank's ncclCommInitRank; (b) ONE rank fails before the collective
+    phase -> nobody enters it (no id broadcast, no ncclCommInitRank) and all ranks agree on the fallback."""
+    import torch.distributed as dist
+    from shapy_amd import parallel, rccl
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if force:
+        os.environ['SHAPY_RCCL_FORCE_FAIL'] = force
+    dist.init_process_group('gloo', init_method='env://')
+    fake = _FakeRccl(rank)
+    rccl._load = lambda: fake
+    g = parallel.BetasGatherer(world)
+    g._fallback_group = lambda: 'c10d-fallback-group'          # (no NCCL backend without GPUs)
+    # a sub-group whose rank 0 is NOT the world's rank 0 exercises the broadcast source as well
+    ok = g._init_rccl()
+    q.put((rank, ok, g.mode, g.group, list(fake.calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('force', ['', 'rank1', 'rank0'])
+def test_rccl_two_phase_init_on_gloo_with_stubbed_librccl(force):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + {'': 0, 'rank1': 1, 'rank0': 2}[force]
+    procs = [ctx.Process(target=_rccl_init_worker, args=(r, 2, port, q, force)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)       # a hang here = mismatched collectives
+    for p in procs:
+        p.join(60)
+    uid = bytes(range(100, 228))
+    if not force:
+        assert [r[1:4] for r in res] == [(True, 'lane', None)] * 2
+        assert res[0][4] == ['id', ('init', 2, 0, uid)] and res[1][4] == [('init', 2, 1, uid)]
+    else:
+        assert [r[1:4] for r in res] == [(False, 'work', 'c10d-fallback-group')] * 2
+        assert not any(c[0] == 'init' for r in res for c in r[4] if isinstance(c, tuple))
+
+
+def test_rccl_broadcast_source_is_the_groups_first_rank():
+    """RcclComm.connect broadcasts the id from the GROUP's rank 0 as a global rank."""
+    import inspect
+    from shapy_amd import rccl
+    src = inspect.getsource(rccl.RcclComm.connect)
+    assert 'get_global_rank(self.group, 0)' in src and 'src=src' in src
 
 
 def test_dp_sharding_and_allgather_gloo():
@@ -652,14 +723,19 @@ def test_winograd_guard_keeps_the_callers_layer_overrides(hrnet):
     every call (every rank compiles the same plan)."""
     keep = dict(hrnet.layer_algo), dict(hrnet._guard_demotions)
     try:
-        hrnet.layer_algo = {'stage2.0.branches.0.0.conv1': 'direct'}              # the caller's
-        for name, to in (('stage3.0.branches.1.0.conv2', 'winograd'), ('stage3.1.branches.2.1.conv1', 'direct')):
-            hrnet.layer_algo[name] = to                                            # what calibrate() does
-            hrnet._guard_demotions[name] = to
+        hrnet.layer_algo = {'stage2.0.branches.0.0.conv1': 'direct',              # the caller's
+                            'stage4.0.branches.3.0.conv1': 'winograd'}
+        hrnet._guard_demotions = {}
+        for name, to in (('stage3.0.branches.1.0.conv2', 'winograd'), ('stage3.1.branches.2.1.conv1', 'direct'),
+                         ('stage4.0.branches.3.0.conv1', 'direct')):             # ... over a caller's entry
+            hrnet._guard_demote(name, to)                                          # what calibrate() does
+        hrnet._guard_demote('stage4.0.branches.3.0.conv1', 'direct')              # (a second pass)
+        assert hrnet.layer_algo['stage4.0.branches.3.0.conv1'] == 'direct'
         hrnet.layer_algo['stage3.0.branches.1.0.conv2'] = 'direct'                # caller tightens one
         hrnet._drop_guard_demotions()
         assert hrnet.layer_algo == {'stage2.0.branches.0.0.conv1': 'direct',
-                                    'stage3.0.branches.1.0.conv2': 'direct'}
+                                    'stage3.0.branches.1.0.conv2': 'direct',
+                                    'stage4.0.branches.3.0.conv1': 'winograd'}    # the caller's value is back
         assert hrnet._guard_demotions == {}
         x = torch.zeros(3, 3, 64, 96)
         p1, p2 = hrnet._guard_probe(x), hrnet._guard_probe(x)
@@ -681,7 +757,7 @@ def test_rccl_binding_loads_and_bench_counts_launch_groups(hrnet):
         assert hasattr(lib, sym)
     assert ctypes_sizeof_unique_id() == 128
     g = parallel.BetasGatherer(1)
-    assert g.mode == 'rccl' and g(torch.ones(2, 10)).shape == (2, 10)      # one rank, not forced: identity
+    assert g.mode == 'lane' and g(torch.ones(2, 10)).shape == (2, 10)      # one rank, not forced: identity
     with pytest.raises(ValueError):
         parallel.BetasGatherer(2, mode='nonsense')
     keep = hrnet.conv_algo, hrnet.wino4_min_hw, hrnet.group_branches

@@ -4,7 +4,7 @@ What it checks is the host logic the GPU tests can only check together with the 
 `HighResolutionNet._compile` hands to `shapy_hrnet_run` (the ctypes `ShapyOp` array, exactly what the
 executor in csrc/hrnet_ops.hip reads), the packed weight blob and the packed per-image workspace -- buffer
 offsets, row strides and channel offsets, residual aliasing (in-place accumulation of the fuse layers),
-upsample terms, the concat buffer of the head, the FUSEADD op.  Every op is restated with torch CPU ops on
+upsample terms, the concat buffer of the head.  Every op is restated with torch CPU ops on
 ONE flat float32 workspace laid out as the executor addresses it (buffer = ws + off * B), in plan order
 (= enqueue order: one legal schedule of the event-driven plan), always from the op's direct-convolution
 weights (`wgt_off`; a Winograd layer's transformed filters are the kernel tests' business).
@@ -60,20 +60,6 @@ def replay(eng, x):
             if a.relu:
                 y = F.relu(y)
             rows(a.out_off, n_pix, a.out_ld)[:, a.out_coff:a.out_coff + a.Cout] = y
-        elif a.type == _lib.OP_FUSEADD:
-            n_pix = a.Ho * a.Wo
-            y = rows(a.res_off, n_pix, a.res_ld)[:, a.res_coff:a.res_coff + a.Cout].reshape(
-                B, a.Ho, a.Wo, a.Cout).clone()
-            if a.wino_off >= 0:                         # second full-resolution term (fuse_add = 2)
-                y = y + rows(a.wino_off, n_pix, a.Cout).reshape(B, a.Ho, a.Wo, a.Cout)
-            for t, off in enumerate((a.in_off, a.wgt_off, a.bias_off)[:a.ksize]):
-                f = 2 << t
-                assert off >= 0 and a.Ho % f == 0 and a.Wo % f == 0
-                lo = rows(off, (a.Ho // f) * (a.Wo // f), a.Cout).reshape(B, a.Ho // f, a.Wo // f, a.Cout)
-                y = y + up(lo, f)
-            if a.relu:
-                y = F.relu(y)
-            rows(a.out_off, n_pix, a.out_ld)[:, a.out_coff:a.out_coff + a.Cout] = y.reshape(-1, a.Cout)
         elif a.type == _lib.OP_MEANPOOL:
             feats = rows(a.in_off, a.Hi * a.Wi, a.in_ld)[:, :a.Cin].reshape(B, a.Hi * a.Wi, a.Cin).mean(1)
         else:
@@ -97,33 +83,24 @@ def seeded():
     return net, x, ref
 
 
-@pytest.mark.parametrize('dag,fuse_add,lanes', [(True, 0, None), (True, 1, None), (False, 1, None),
-                                                ('grouped', 1, None),
-                                                (True, 2, 'dest,dest,mixed'), (True, 2, 'source,source,source'),
-                                                ('grouped', 2, None)])
-def test_compiled_plan_replayed_on_the_cpu_equals_the_oracle(seeded, dag, fuse_add, lanes):
+@pytest.mark.parametrize('dag', [True, False, 'grouped'])
+def test_compiled_plan_replayed_on_the_cpu_equals_the_oracle(seeded, dag):
     net, x, ref = seeded
-    keep = net.dag, net.fuse_add, net.multi_stream, net.fuse_chain_lanes, net.group_branches, net.conv_algo
+    keep = net.dag, net.multi_stream, net.group_branches, net.conv_algo
     try:
-        net.dag, net.fuse_add, net.multi_stream = bool(dag), fuse_add, True
+        net.dag, net.multi_stream = bool(dag), True
         net.conv_algo = 'direct'   # (the replay reads the direct weights: no need to transform 209 filters)
         if dag == 'grouped':       # persistent launch groups per depth level (needs the F(4x4) layers)
             net.group_branches, net.conv_algo = True, 'winograd4'
-        if lanes:
-            net.fuse_chain_lanes = lanes
         eng = net._compile(64, 64, torch.device('cpu'))
     finally:
-        net.dag, net.fuse_add, net.multi_stream, net.fuse_chain_lanes, net.group_branches, net.conv_algo = keep
+        net.dag, net.multi_stream, net.group_branches, net.conv_algo = keep
     from shapy_amd import _lib
-    n_add = sum(1 for a in eng['ops'][:eng['n_ops']] if a.type == _lib.OP_FUSEADD)
     n_ups = sum(1 for a in eng['ops'][:eng['n_ops']] if a.type == _lib.OP_CONV and a.ups > 1)
-    # upsample terms of W48: stage 2: 1, stage 3: 4 x 3, stage 4: 3 x 6; outputs with such terms: 1 + 8 + 9;
-    # all outputs: 2 + 12 + 12
-    deferred = fuse_add == 2
+    # upsample terms of W48: stage 2: 1, stage 3: 4 x 3, stage 4: 3 x 6
     if dag == 'grouped':
         assert sum(1 for a in eng['ops'][:eng['n_ops']] if a.group > 1) >= 8      # (64 x 64: stage 2 only)
-    assert (n_add, n_ups) == ((26, 0) if deferred else (18, 0) if fuse_add else (0, 31))
-    assert eng['n_ops'] == 332 + n_add
+    assert n_ups == 31 and eng['n_ops'] == 332
     with torch.no_grad():
         feats = replay(eng, x)
     assert feats.shape == ref.shape and torch.isfinite(feats).all()

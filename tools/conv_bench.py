@@ -69,7 +69,7 @@ def main():
         wu = wu4 = None
         for tile in args.tiles.split(','):
             d = _lib.ShapyConv()
-            if tile in ('wino4', 'wino4u12') or tile.startswith('wino4s'):   # Winograd F(4x4,3x3) (conv_wino4.hip); wino4sN: start stagger N
+            if tile == 'wino4' or tile.startswith('wino4k'):   # Winograd F(4x4,3x3) (conv_wino4.hip); wino4kS: split-K, S slices
                 from shapy_amd.utils import winograd
                 if args.dtype != 'f32' or not winograd.eligible4(ks, st, pad, Cin, Cout, ups) \
                         or min(Hi, Wi) < args.wino4_min_hw:
@@ -92,12 +92,18 @@ def main():
             d.ksize, d.stride, d.pad = ks, st, pad
             d.out_ld = Cout; d.out_coff = 0; d.res_ld = Cout if has_res else 0; d.res_coff = 0
             d.relu = int(relu); d.ups = ups
-            if tile.startswith('wino4s'):
-                d.tile = _lib.TILE_WINO4 | _lib.tile_w4_stagger(int(tile[6:]))
+            if tile.startswith('wino4k'):
+                S = int(tile[6:])
+                if (Cin // 16) % S:
+                    continue
+                slab, ncnt = _lib.w4_split_sizes(Hi, Wi, Cout, S)
+                split_ws = torch.empty(slab * B, device='cuda')
+                split_cnt = torch.zeros(ncnt * B, dtype=torch.int32, device='cuda')
+                d.split_ws, d.split_cnt = split_ws.data_ptr(), split_cnt.data_ptr()
+                d.tile = _lib.TILE_WINO4 | _lib.tile_w4_ksplit(S)
             else:
                 d.tile = {'wino': 0, 'wino1': 0x4000, 'wino2': 0x8000, 'winochunk': 0x20000,
-                          'wino4': _lib.TILE_WINO4,
-                          'wino4u12': _lib.TILE_WINO4 | _lib.TILE_WINO4_UNROLL12}[tile] if tile.startswith('wino') else _lib.TILES[tile]
+                          'wino4': _lib.TILE_WINO4}[tile] if tile.startswith('wino') else _lib.TILES[tile]
             d.dtype = {'f32': _lib.DTYPE_F32, 'bf16': _lib.DTYPE_BF16, 'f32x6': _lib.DTYPE_F32X6}[args.dtype]
             rc = 0
             for _ in range(2):

@@ -1,6 +1,6 @@
 """Per HighResolutionModule of a verbose timeline (tools/timeline.py --verbose): when each branch lane
 finishes, how late each lane's first branch conv starts after the lane's previous kernel, and how long the
-fuse phase runs behind the last branch -- the numbers behind DESIGN section 8 (`fuse_add`).
+fuse phase runs behind the last branch -- the numbers behind DESIGN section 8.
 
     python tools/module_tails.py profiles/r04o_timeline_multistream_dag_verbose.txt
 """
@@ -17,7 +17,7 @@ def main():
             rows.append((int(m[1]), float(m[2]), float(m[2]) + float(m[3]), m[4]))
     mods = collections.OrderedDict()
     for lane, t0, t1, name in rows:
-        m = re.match(r'(stage\d\.\d)\.(branches|fuse_layers|fuse_add)\.(\d)', name)
+        m = re.match(r'(stage\d\.\d)\.(branches|fuse_layers)\.(\d)', name)
         if m:
             mods.setdefault(m[1], []).append((lane, t0, t1, m[2], int(m[3]), name))
     prev_end = collections.defaultdict(float)          # lane -> end of its last kernel before the module

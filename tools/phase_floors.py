@@ -45,10 +45,6 @@ def main():
         if o['type'] == _lib.OP_MEANPOOL:
             ph['bytes'] += 4.0 * B * o['Hi'] * o['Wi'] * o['Cin']
             continue
-        if o['type'] == _lib.OP_FUSEADD:                     # base + output once, the small terms
-            terms = sum(1.0 / 4 ** (t + 1) for t in range(o['ksize']))
-            ph['bytes'] += 4.0 * B * o['Ho'] * o['Wo'] * o['Cout'] * (2.0 + terms)
-            continue
         cc = o['Cout'] * o['Cin']
         if o['type'] == _lib.OP_STEM:
             macs = o['Ho'] * o['Wo'] * cc * 9

@@ -27,8 +27,6 @@ def main():
     ap.add_argument('--verbose', action='store_true')
     ap.add_argument('--no-dag', action='store_true', help='the traced run used SHAPY_DAG=0 or --single-stream')
     ap.add_argument('--group', type=int, default=None, help='group_branches of the traced run (default: the product default)')
-    ap.add_argument('--fuse-add', type=int, default=None, help='fuse_add of the traced run (0 | 1 | 2)')
-    ap.add_argument('--fuse-chain-lanes', default=None)
     args = ap.parse_args()
     import torch                                                   # noqa: F401
     import __graft_entry__ as ge
@@ -37,10 +35,6 @@ def main():
         net.backbone.conv_algo = args.algo
     if args.group is not None:
         net.backbone.group_branches = bool(args.group)
-    if args.fuse_add is not None:
-        net.backbone.fuse_add = args.fuse_add
-    if args.fuse_chain_lanes:
-        net.backbone.fuse_chain_lanes = args.fuse_chain_lanes
     net.backbone._dag_eff = net.backbone.dag and not args.no_dag        # the traced run: eager, multi-stream
     plan = net.backbone._build_plan(args.size, args.size)
     # one kernel per op, except launch groups (one persistent kernel for `group` ops): the group's
@@ -57,8 +51,7 @@ def main():
     f = glob.glob(args.out + '/**/*kernel_trace.csv', recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f))]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
-    ks = [r for r in rows if 'conv_' in r['Kernel_Name'] or 'mean_pool' in r['Kernel_Name']
-          or 'fuse_add' in r['Kernel_Name']]
+    ks = [r for r in rows if 'conv_' in r['Kernel_Name'] or 'mean_pool' in r['Kernel_Name']]
     n = len(ops)
     # a forward starts with the stem kernel; anything after its n backbone kernels (the SMPL-X
     # blend-shape GEMMs run on the same conv kernel) is not part of the plan

@@ -18,7 +18,6 @@ from shapy_amd import _lib  # noqa: E402
 from shapy_amd.utils import winograd  # noqa: E402
 
 
-STAGGER = {'n': 0}      # --stagger: start delay of a CU's second workgroup (units of 128 clocks)
 
 
 def make_desc(B, H, W, C, O, res, relu, coff=0, extra_ld=0, g=None):
@@ -38,7 +37,7 @@ def make_desc(B, H, W, C, O, res, relu, coff=0, extra_ld=0, g=None):
     d.Ho, d.Wo, d.Cout = H, W, O
     d.ksize, d.stride, d.pad = 3, 1, 1
     d.out_ld = ld; d.out_coff = coff; d.res_ld = ld if res else 0; d.res_coff = coff if res else 0
-    d.relu = int(relu); d.ups = 1; d.tile = _lib.TILE_WINO4 | _lib.tile_w4_stagger(STAGGER['n'])
+    d.relu = int(relu); d.ups = 1; d.tile = _lib.TILE_WINO4
     d.wgt_wino = wu.data_ptr()
     return d, dict(x=x, w=w, b=b, wu=wu, r=r, out=out)
 
@@ -81,9 +80,7 @@ def main():
     ap.add_argument('--bench', action='store_true')
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--stagger', type=int, default=0)
     args = ap.parse_args()
-    STAGGER['n'] = args.stagger
     lib = _lib.load()
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     ok = True
