@@ -267,25 +267,6 @@ def test_regressor_collapse_is_the_same_affine_map():
         MLP(8, 4, layers=[8], activation={'type': 'relu'}, normalization={'type': 'none'}).collapse()
 
 
-def test_pack_aligns_before_the_gap_test():
-    """first-fit packing with sizes that are not multiples of 8 -- the aligned offset
-    must be the one tested against the next live buffer."""
-    from shapy_amd.models.backbone.hrnet import _Buf, _pack
-    r = np.random.default_rng(0)
-    for _ in range(50):
-        items = []
-        for k in range(12):
-            a = int(r.integers(0, 10))
-            b = _Buf(1, 1, int(r.integers(1, 40)))
-            items.append((a, a + int(r.integers(0, 5)), b.size, b))
-        total = _pack(items)
-        for i, (s0, e0, z0, b0) in enumerate(items):
-            assert b0.off % 8 == 0 and b0.off + z0 <= total
-            for (s1, e1, z1, b1) in items[i + 1:]:
-                if s0 <= e1 and s1 <= e0:                      # live at the same time
-                    assert b0.off + z0 <= b1.off or b1.off + z1 <= b0.off
-
-
 def test_train_mode_is_refused(hrnet):
     hrnet.train()
     try:
