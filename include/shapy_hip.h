@@ -245,7 +245,7 @@ int shapy_regressor_collapsed_f32(const float *features, const float *W_all, con
  * ------------------------------------------------------------------------------------- */
 typedef struct ShapySmplxModel {
   int32_t V, J, NB;             /* vertices, joints (55), shape comps incl. expression      */
-  int32_t P;                    /* pose-feature dim = (J-1)*9, Ppad = round_up(P,16)         */
+  int32_t P;                    /* pose-feature dim = (J-1)*9, Ppad = round_up(P,32)         */
   int32_t Ppad, NBpad;          /* K paddings of the two GEMMs                               */
   int32_t n_static_lmk, n_dyn_lmk, n_dyn_rows, n_neck;
   const int32_t *parents;       /* [J], parents[0] = -1                                      */
@@ -315,14 +315,17 @@ int shapy_smplx_joints_f32(const ShapySmplxModel *model_host, const float *posed
                            int use_face_contour, void *stream);
 
 /* Argument glue of SMPLX.forward (body_models.py:660-700) in one launch: up to 7 pose parts of
- * rotation matrices ([B, n_joints_host[k], 3, 3] device pointers in the HOST array parts_host; a NULL
- * part is identity) concatenated into pose_out [B, sum n, 3, 3]; betas [B, nb] (+ expression [B, ne],
- * NULL = none) into coeffs_out [B, NBpad] (zero padded) and, when coeffs_shape_out is given, the same
- * row with the expression part zeroed. */
-int shapy_smplx_prepare_f32(const float *const *parts_host, const int32_t *n_joints_host, int n_parts,
-                            const float *betas, int nb, const float *expression, int ne, int NBpad,
-                            float *pose_out, float *coeffs_out, float *coeffs_shape_out, int B,
-                            void *stream);
+ * rotation matrices (device pointers in the HOST array parts_host, part k = [B, n_joints_host[k], 3, 3]
+ * with contiguous joints and part_bstride_host[k] floats between consecutive bodies -- 0 = one row
+ * broadcast to every body, NULL array = dense; slices such as rot[:, 1:] need no copy; a NULL part is
+ * identity) concatenated into pose_out [B, sum n, 3, 3]; betas (rows of nb floats, betas_bstride apart;
+ * 0 = one row for all) (+ expression, rows of ne floats, NULL = none) into coeffs_out [B, NBpad] (zero
+ * padded) and, when coeffs_shape_out is given, the same row with the expression part zeroed. */
+int shapy_smplx_prepare_f32(const float *const *parts_host, const int32_t *n_joints_host,
+                            const int64_t *part_bstride_host, int n_parts, const float *betas,
+                            int64_t betas_bstride, int nb, const float *expression,
+                            int64_t expr_bstride, int ne, int NBpad, float *pose_out, float *coeffs_out,
+                            float *coeffs_shape_out, int B, void *stream);
 
 /* The whole SMPL-X layer (SMPLX.forward, models/body_models/body_models.py:628-767, on prepared
  * inputs) in ONE call: shape blend GEMM(s), pose decode + joint regression + kinematic chain, pose

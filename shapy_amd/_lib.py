@@ -121,9 +121,9 @@ SIGNATURES = {
                                             ctypes.c_int, vp]),
     'shapy_smplx_joints_f32': (ctypes.c_int, [ctypes.POINTER(ShapySmplxModel), vp, vp, vp, vp, vp,
                                               vp, vp, ctypes.c_int, ctypes.c_int, vp]),
-    'shapy_smplx_prepare_f32': (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32), ctypes.c_int, vp,
-                                               ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp,
-                                               ctypes.c_int, vp]),
+    'shapy_smplx_prepare_f32': (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32),
+                                               ctypes.POINTER(ctypes.c_int64), ctypes.c_int, vp, i64, ctypes.c_int,
+                                               vp, i64, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp]),
     'shapy_smplx_forward_f32': (ctypes.c_int, [ctypes.POINTER(ShapySmplxModel), vp, ctypes.c_int,
                                                ctypes.c_int] + [vp] * 15 +
                                 [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),

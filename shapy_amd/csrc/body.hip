@@ -156,14 +156,37 @@ __global__ __launch_bounds__(64) void smplx_pose_kernel(PoseK k) {
       k.rot[((long)b * k.J + j) * 9 + i] = r[i];
     }
     // rest joints: J = J_template + J_shapedirs . coeffs   (== J_regressor (v_template + S c))
+    // One fmaf chain per axis in coefficient order, as before -- but the three rows of this joint are
+    // walked together and four coefficients at a time, so that 15 loads are in flight instead of one
+    // (the loop used to be 3 x NB dependent global loads: most of the kernel's 25 us at B = 64).
     const float *c = k.coeffs + (long)b * k.NBpad;
+    const float *js = k.Js + (long)j * 3 * k.NB;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    int l = 0;
+    for (; l + 4 <= k.NB; l += 4) {
+      float cv[4], a0[4], a1[4], a2[4];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float *js = k.Js + ((long)j * 3 + a) * k.NB;
-      float s = 0.f;
-      for (int l = 0; l < k.NB; ++l) s = fmaf(js[l], c[l], s);
-      Jl[j * 3 + a] = k.Jt[j * 3 + a] + s;
+      for (int q = 0; q < 4; ++q) {
+        cv[q] = c[l + q];
+        a0[q] = js[l + q];
+        a1[q] = js[k.NB + l + q];
+        a2[q] = js[2 * k.NB + l + q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s0 = fmaf(a0[q], cv[q], s0);
+        s1 = fmaf(a1[q], cv[q], s1);
+        s2 = fmaf(a2[q], cv[q], s2);
+      }
     }
+    for (; l < k.NB; ++l) {
+      s0 = fmaf(js[l], c[l], s0);
+      s1 = fmaf(js[k.NB + l], c[l], s1);
+      s2 = fmaf(js[2 * k.NB + l], c[l], s2);
+    }
+    Jl[j * 3 + 0] = k.Jt[j * 3 + 0] + s0;
+    Jl[j * 3 + 1] = k.Jt[j * 3 + 1] + s1;
+    Jl[j * 3 + 2] = k.Jt[j * 3 + 2] + s2;
     // pose feature (lbs.py:176): (R[1:] - I) flattened
     if (j >= 1) {
 #pragma unroll
@@ -243,33 +266,95 @@ __global__ __launch_bounds__(64) void smplx_pose_kernel(PoseK k) {
 }
 
 // ------------------------------------------------------------------------------------------
-// skinning (lbs.py:187-190): one thread per (body, vertex); A[b] staged in LDS
+// skinning (lbs.py:187-190): T[b,v] = sum_j W[v,j] A[b,j] (3x4), vertices = T [v_posed; 1].
+// One thread owns NV vertices (256 apart) and NBODY consecutive bodies.  The transforms A[b][j] sit in LDS
+// and are read as broadcasts -- which cost the LDS pipe a full 1 KB pass per wave instruction all the
+// same, so the register block has to amortise them: 4 vertices x 2 bodies = 6 ds_read_b128 per 48
+// v_pk_fma_f32 and joint, LDS and VALU pipes level.  (Round 5, first form: 1 vertex x 4 bodies, 12 reads per
+// 24 FMAs: 24.0 us at B = 64, exactly the LDS bound; round 4: 1 x 1, 21.7 us.)  The weights W[j][v]
+// (coalesced over v) are requested five joints ahead.  Per output the sum runs over the joints in index order
+// -- the same fmaf chain as one thread per (body, vertex).
 // ------------------------------------------------------------------------------------------
+template <int NV, int NBODY>
 __global__ __launch_bounds__(256) void smplx_skin_kernel(const float *__restrict__ Wt,
                                                          const float *__restrict__ A,
                                                          const float *__restrict__ v_posed,
-                                                         float *__restrict__ out, int V, int J) {
-  __shared__ float As[64 * 12];
-  const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < J * 12; i += 256) As[i] = A[(long)b * J * 12 + i];
-  __syncthreads();
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= V) return;
-  float T[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) T[i] = 0.f;
-  for (int j = 0; j < J; ++j) {
-    const float w = Wt[(long)j * V + v];
-    const float *a = As + j * 12;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = fmaf(w, a[i], T[i]);
+                                                         float *__restrict__ out, int V, int J, int B) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) float As[NBODY][64 * 12];
+  const int b0 = blockIdx.y * NBODY;
+  for (int i = threadIdx.x; i < NBODY * J * 12; i += 256) {
+    const int q = i / (J * 12), r = i % (J * 12);
+    const int b = b0 + q < B ? b0 + q : B - 1;            // (tail bodies: a copy of the last one, never stored)
+    As[q][r] = A[(long)b * J * 12 + r];
   }
-  const float *p = v_posed + ((long)b * V + v) * 3;
-  const float x = p[0], y = p[1], z = p[2];
-  float *o = out + ((long)b * V + v) * 3;
-  o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
-  o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
-  o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+  __syncthreads();
+  const int v0 = blockIdx.x * (256 * NV) + threadIdx.x;
+  int vi[NV];                                             // (clamped: out-of-range vertices are never stored)
+#pragma unroll
+  for (int u = 0; u < NV; ++u) vi[u] = v0 + 256 * u < V ? v0 + 256 * u : V - 1;
+  f32x2 T[NV][NBODY][6];
+#pragma unroll
+  for (int u = 0; u < NV; ++u)
+#pragma unroll
+    for (int q = 0; q < NBODY; ++q)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) T[u][q][i] = f32x2{0.f, 0.f};
+  // weights a whole group of JG joints ahead: there are only ~1.4 waves per SIMD at B = 64, so nothing else
+  // hides the ~700-cycle L2 latency -- with one joint of lookahead (192 cycles of FMAs) the kernel took 25.9 us
+  // whatever the register block
+  constexpr int JG = 5;
+  float wn[JG][NV];
+  auto wload = [&](int j0) {
+#pragma unroll
+    for (int g = 0; g < JG; ++g) {
+      const int j = j0 + g < J ? j0 + g : J - 1;
+#pragma unroll
+      for (int u = 0; u < NV; ++u) wn[g][u] = Wt[(long)j * V + vi[u]];
+    }
+  };
+  wload(0);
+  for (int j0 = 0; j0 < J; j0 += JG) {
+    float w[JG][NV];
+#pragma unroll
+    for (int g = 0; g < JG; ++g)
+#pragma unroll
+      for (int u = 0; u < NV; ++u) w[g][u] = wn[g][u];
+    if (j0 + JG < J) wload(j0 + JG);
+#pragma unroll
+    for (int g = 0; g < JG; ++g) {
+      if (j0 + g >= J) break;                             // (uniform)
+#pragma unroll
+      for (int q = 0; q < NBODY; ++q) {
+        const f32x4 *a = reinterpret_cast<const f32x4 *>(&As[q][(j0 + g) * 12]);
+        const f32x4 a0 = a[0], a1 = a[1], a2 = a[2];
+        const f32x2 av[6] = {f32x2{a0[0], a0[1]}, f32x2{a0[2], a0[3]}, f32x2{a1[0], a1[1]},
+                             f32x2{a1[2], a1[3]}, f32x2{a2[0], a2[1]}, f32x2{a2[2], a2[3]}};
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+          const f32x2 ww = f32x2{w[g][u], w[g][u]};
+#pragma unroll
+          for (int i = 0; i < 6; ++i) T[u][q][i] = __builtin_elementwise_fma(ww, av[i], T[u][q][i]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int v = v0 + 256 * u;
+    if (v >= V) break;
+#pragma unroll
+    for (int q = 0; q < NBODY; ++q) {
+      const int b = b0 + q;
+      if (b >= B) break;
+      const float *p = v_posed + ((long)b * V + v) * 3;
+      const float x = p[0], y = p[1], z = p[2];
+      float *o = out + ((long)b * V + v) * 3;
+      o[0] = T[u][q][0][0] * x + T[u][q][0][1] * y + T[u][q][1][0] * z + T[u][q][1][1];
+      o[1] = T[u][q][2][0] * x + T[u][q][2][1] * y + T[u][q][3][0] * z + T[u][q][3][1];
+      o[2] = T[u][q][4][0] * x + T[u][q][4][1] * y + T[u][q][5][0] * z + T[u][q][5][1];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -406,9 +491,11 @@ __global__ void head_prepare_kernel(PrepK k) {
 // expression, coeffs_shape (the same with the expression part zeroed).
 struct SmplxPrepK {
   const float *part[7];
+  long bs[7];                    // floats between consecutive bodies of part k (0: one row for all)
   int n[7], first[7];            // joints of part k, index of its first joint
   int n_parts, n_pose, B, nb, ne, NBpad;
   const float *betas, *expr;
+  long betas_bs, expr_bs;        // floats between consecutive rows (0: one row for all)
   float *pose, *coeffs, *coeffs_shape;
 };
 
@@ -424,14 +511,14 @@ __global__ void smplx_prepare_kernel(SmplxPrepK k) {
 #pragma unroll
     for (int p = 0; p < 7; ++p)
       if (p < k.n_parts && k.part[p] && j >= k.first[p] && j < k.first[p] + k.n[p])
-        v = k.part[p][(b * k.n[p] + (j - k.first[p])) * 9 + q];
+        v = k.part[p][b * k.bs[p] + (j - k.first[p]) * 9 + q];
     k.pose[i] = v;
   } else if (i < n_rot + n_co) {
     const long r = i - n_rot;
     const int c = (int)(r % k.NBpad);
     const long b = r / k.NBpad;
-    const float sh = (c < k.nb && k.betas) ? k.betas[b * k.nb + c] : 0.f;
-    const float ex = (c >= k.nb && c < k.nb + k.ne && k.expr) ? k.expr[b * k.ne + (c - k.nb)] : 0.f;
+    const float sh = (c < k.nb && k.betas) ? k.betas[b * k.betas_bs + c] : 0.f;
+    const float ex = (c >= k.nb && c < k.nb + k.ne && k.expr) ? k.expr[b * k.expr_bs + (c - k.nb)] : 0.f;
     k.coeffs[r] = c < k.nb ? sh : ex;
     if (k.coeffs_shape) k.coeffs_shape[r] = sh;
   }
@@ -555,8 +642,13 @@ extern "C" int shapy_smplx_skin_f32(const ShapySmplxModel *m, const float *A, co
                                     float *vertices_out, int B, void *stream) {
   if (B <= 0) return SHAPY_OK;
   if (m->J > 64) return SHAPY_EINVAL;
-  hipLaunchKernelGGL(smplx_skin_kernel, dim3((m->V + 255) / 256, B), dim3(256), 0,
-                     (hipStream_t)stream, m->lbs_weights_t, A, v_posed, vertices_out, m->V, m->J);
+  // register block 4 vertices x 2 bodies once there are enough bodies to keep every CU busy with it
+  if (B >= 16)
+    hipLaunchKernelGGL((smplx_skin_kernel<4, 2>), dim3((m->V + 1023) / 1024, (B + 1) / 2), dim3(256), 0,
+                       (hipStream_t)stream, m->lbs_weights_t, A, v_posed, vertices_out, m->V, m->J, B);
+  else
+    hipLaunchKernelGGL((smplx_skin_kernel<1, 1>), dim3((m->V + 255) / 256, B), dim3(256), 0,
+                       (hipStream_t)stream, m->lbs_weights_t, A, v_posed, vertices_out, m->V, m->J, B);
   return (int)hipGetLastError();
 }
 
@@ -601,21 +693,31 @@ extern "C" int shapy_smplx_forward_f32(const ShapySmplxModel *m, const float *po
   if (B <= 0) return SHAPY_OK;
   hipStream_t s = (hipStream_t)stream;
   const int N = m->V * 3;
-  int rc = smplx_gemm(coeffs, B, m->NBpad, m->shapedirs_t, N, v_shaped_full, m->v_template, nullptr, s);
-  if (rc) return rc;
-  if (coeffs_shape) {
-    if (!v_shaped) return SHAPY_EINVAL;
-    rc = smplx_gemm(coeffs_shape, B, m->NBpad, m->shapedirs_t, N, v_shaped, m->v_template, nullptr, s);
+  if (coeffs_shape && !v_shaped) return SHAPY_EINVAL;
+  int rc;
+  if (coeffs_shape && coeffs_shape == coeffs + (size_t)B * m->NBpad && v_shaped == v_shaped_full + (size_t)B * N) {
+    // both coefficient sets and both outputs are adjacent (SMPLX.forward lays them out that way): ONE
+    // GEMM with M = 2 B -- the shape basis is streamed once and one launch goes away
+    rc = smplx_gemm(coeffs, 2 * B, m->NBpad, m->shapedirs_t, N, v_shaped_full, m->v_template, nullptr, s);
     if (rc) return rc;
+  } else {
+    rc = smplx_gemm(coeffs, B, m->NBpad, m->shapedirs_t, N, v_shaped_full, m->v_template, nullptr, s);
+    if (rc) return rc;
+    if (coeffs_shape) {
+      rc = smplx_gemm(coeffs_shape, B, m->NBpad, m->shapedirs_t, N, v_shaped, m->v_template, nullptr, s);
+      if (rc) return rc;
+    }
   }
   if (shape_only) return SHAPY_OK;
   rc = shapy_smplx_pose_f32(m, pose, pose_type, n_pose, coeffs, rot, pose_feat, A, posed_joints,
                             dyn_row, B, stream);
   if (rc) return rc;
-  // (M = batch is skinny: every workgroup walks its 31 K chunks of posedirs alone -- three chunks of
-  // loads in flight, tile flag 0x40000, instead of one; SHAPY_SMPLX_PD1=1 restores one for A/B runs)
-  static const int pd_flag = getenv("SHAPY_SMPLX_PD1") ? 0 : 0x40000;
-  rc = smplx_gemm(pose_feat, B, m->Ppad, m->posedirs_t, N, v_posed, nullptr, v_shaped_full, s, pd_flag);
+  // M = batch is skinny and posedirs (61 MB) is streamed exactly once: the 32 x 64 tile with 128-byte K
+  // chunks (Ppad % 32 == 0) is the fastest of the sweep at every batch size -- 26.0 us at B = 64, 16.6 at
+  // B = 4 against 34.4 / 30.8 for round 4's 64 x 48 tile with three chunks of loads in flight
+  // (tools/skinny_gemm_bench.py, profiles/r05e_skinny_gemm_b{4,64}.txt)
+  const int pose_tile = (m->Ppad % 32 == 0) ? SHAPY_TILE_32x64 : 0x40000;
+  rc = smplx_gemm(pose_feat, B, m->Ppad, m->posedirs_t, N, v_posed, nullptr, v_shaped_full, s, pose_tile);
   if (rc) return rc;
   rc = shapy_smplx_skin_f32(m, A, v_posed, vertices, B, stream);
   if (rc) return rc;
@@ -653,9 +755,10 @@ extern "C" int shapy_head_prepare_f32(const float *params, int S, int B, int P, 
 }
 
 extern "C" int shapy_smplx_prepare_f32(const float *const *parts_host, const int32_t *n_joints_host,
-                                       int n_parts, const float *betas, int nb, const float *expression,
-                                       int ne, int NBpad, float *pose_out, float *coeffs_out,
-                                       float *coeffs_shape_out, int B, void *stream) {
+                                       const int64_t *part_bstride_host, int n_parts, const float *betas,
+                                       int64_t betas_bstride, int nb, const float *expression,
+                                       int64_t expr_bstride, int ne, int NBpad, float *pose_out,
+                                       float *coeffs_out, float *coeffs_shape_out, int B, void *stream) {
   if (B <= 0) return SHAPY_OK;
   if (n_parts < 0 || n_parts > 7 || nb < 0 || ne < 0 || nb + ne > NBpad || !coeffs_out ||
       (n_parts > 0 && (!parts_host || !n_joints_host || !pose_out)))
@@ -665,10 +768,14 @@ extern "C" int shapy_smplx_prepare_f32(const float *const *parts_host, const int
   for (int p = 0; p < n_parts; ++p) {
     if (n_joints_host[p] < 0) return SHAPY_EINVAL;
     k.part[p] = parts_host[p]; k.n[p] = n_joints_host[p]; k.first[p] = first;
+    k.bs[p] = part_bstride_host ? part_bstride_host[p] : (long)n_joints_host[p] * 9;
+    if (k.bs[p] < 0) return SHAPY_EINVAL;
     first += n_joints_host[p];
   }
   k.n_parts = n_parts; k.n_pose = first; k.B = B; k.nb = nb; k.ne = ne; k.NBpad = NBpad;
   k.betas = betas; k.expr = expression; k.pose = pose_out; k.coeffs = coeffs_out;
+  k.betas_bs = betas_bstride; k.expr_bs = expr_bstride;
+  if (betas_bstride < 0 || expr_bstride < 0) return SHAPY_EINVAL;
   k.coeffs_shape = coeffs_shape_out;
   const long total = (long)B * first * 9 + (long)B * NBpad;
   hipLaunchKernelGGL(smplx_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,

@@ -200,7 +200,7 @@ class SMPLX(VersionedWeights, nn.Module):
         NB = nb + ne
         NBpad = _round_up(NB, 16)
         P = self.posedirs.shape[0]
-        Ppad = _round_up(P, 16)
+        Ppad = _round_up(P, 32)     # 128-byte K chunks of the pose-blend GEMM (csrc/conv_igemm.hip: KQ = 8)
         N = V * 3
         Npad = _round_up(N, 128)
         d64 = lambda t: t.detach().double().cpu()
@@ -255,76 +255,90 @@ class SMPLX(VersionedWeights, nn.Module):
                 jaw_pose=None, betas=None, expression=None, transl=None, leye_pose=None,
                 reye_pose=None, get_skin=True, return_full_pose=False, return_shaped=True,
                 _shape_only=False, **kwargs):
-        """SMPLX.forward (body_models.py:628-767): poses are rotation matrices [B,k,3,3]."""
+        """SMPLX.forward (body_models.py:628-767): poses are rotation matrices [B,k,3,3].
+
+        The call is host-bound (B = 4 and B = 64 take the same time), so the path below avoids torch
+        ops: float32 device tensors whose joints are contiguous go to the glue kernel as they are --
+        pointer + batch stride; slices like ``rot[:, 1:]`` are not copied, batch-1 tensors are
+        broadcast with stride 0 -- and everything else takes the converting route (``dev``)."""
         device = self.shapedirs.device
         _lib.require_cuda(self.shapedirs, 'SMPLX buffers')
-        model_vars = [betas, global_rot, body_pose, transl, left_hand_pose, right_hand_pose,
-                      jaw_pose, leye_pose, reye_pose, expression]
+        parts = ((global_rot, 1), (body_pose, self.NUM_BODY_JOINTS), (jaw_pose, 1), (leye_pose, 1),
+                 (reye_pose, 1), (left_hand_pose, self.NUM_HAND_JOINTS), (right_hand_pose, self.NUM_HAND_JOINTS))
         B = 1
-        for var in model_vars:
-            if var is not None:
-                B = max(B, len(var))
+        for var in (betas, transl, expression):
+            if var is not None and var.shape[0] > B:
+                B = var.shape[0]
+        last = -1                                   # joints after the last given part are identity in the kernel
+        for i, (p_, _) in enumerate(parts):
+            if p_ is not None:
+                last = i
+                if p_.shape[0] > B:
+                    B = p_.shape[0]
         dm = self._device_model(device)
-        f32 = dict(dtype=torch.float32, device=device)
-
-        def eye(n):
-            return torch.eye(3, **f32).view(1, 1, 3, 3).expand(B, n, -1, -1)
-        parts = [(global_rot, 1), (body_pose, self.NUM_BODY_JOINTS), (jaw_pose, 1),
-                 (leye_pose, 1), (reye_pose, 1), (left_hand_pose, self.NUM_HAND_JOINTS),
-                 (right_hand_pose, self.NUM_HAND_JOINTS)]
-        # joints after the last given part are identity inside the kernel (n_pose)
-        last = max([i for i, (p, _) in enumerate(parts) if p is not None], default=-1)
-        given = parts[:last + 1]
-        n_pose = sum(n for _, n in given)
-        # one launch for the whole argument glue (shapy_smplx_prepare_f32) instead of eye / cat /
-        # zeros / slice assignments / clone: 8-10 tiny torch kernels per call
         lib = _lib.load()
         keep = []
 
-        def dev_f32(t, shape):
-            t = t.reshape(shape)
-            if t.shape[0] != B:
-                if t.shape[0] != 1:
-                    raise ValueError(f'batch size mismatch: {t.shape[0]} vs {B}')
-                t = t.expand(B, *t.shape[1:])
-            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
-                t = t.to(**f32).contiguous()
-            keep.append(t)
-            return t
+        def dev(t, inner):
+            """(pointer, floats between bodies) of t viewed as [B or 1, *inner]."""
+            n = 1
+            for q in inner:
+                n *= q
+            ok = (t.dtype == torch.float32 and t.device == device and t.dim() == len(inner) + 1
+                  and tuple(t.shape[1:]) == inner)
+            if ok:                                  # inner dims contiguous?
+                st, expect = t.stride(), 1
+                for d in range(len(inner), 0, -1):
+                    if t.shape[d] != 1 and st[d] != expect:
+                        ok = False
+                        break
+                    expect *= t.shape[d]
+            if not ok:
+                t = t.reshape(t.shape[0], *inner).to(dtype=torch.float32, device=device).contiguous()
+                keep.append(t)
+            if t.shape[0] == B and B > 1:
+                return t.data_ptr(), t.stride(0)
+            if t.shape[0] != 1:
+                raise ValueError(f'batch size mismatch: {t.shape[0]} vs {B}')
+            return t.data_ptr(), 0
         ptrs = (ctypes_vp() * 7)()
         cnts = (ctypes_i32() * 7)()
-        for q, (p_, n) in enumerate(given):
+        strides = (ctypes_i64() * 7)()
+        n_pose = 0
+        for q in range(last + 1):
+            p_, n = parts[q]
             cnts[q] = n
-            ptrs[q] = None if p_ is None else dev_f32(p_, (-1, n, 3, 3)).data_ptr()
+            n_pose += n
+            if p_ is not None:
+                ptrs[q], strides[q] = dev(p_, (n, 3, 3))
         NBpad, nb, ne = dm['NBpad'], dm['nb'], dm['ne']
         has_expr = expression is not None
         # one arena: the coefficient rows FIRST -- they are the A operand of the blend-shape GEMMs, whose
         # kernel wants 16-byte-aligned inputs (conv_prepare), and B * NBpad is a multiple of 4 floats; the
         # pose slice behind them starts aligned too and nothing needs to follow it
         n_co = B * NBpad * (2 if has_expr else 1)
-        assert NBpad % 4 == 0
-        arena = torch.empty(n_co + B * n_pose * 9, **f32)
-        coeffs = arena[:B * NBpad].view(B, NBpad)
-        coeffs_shape = arena[B * NBpad:n_co].view(B, NBpad) if has_expr else None
-        full_pose = arena[n_co:].view(B, n_pose, 3, 3)
-        # (reshape by the tensor's OWN batch: a [1, nb] row broadcasts to B in dev_f32)
-        betas_t = None if betas is None else dev_f32(betas, (betas.shape[0], -1))
-        if betas_t is not None and betas_t.shape[1] != nb:
-            raise ValueError(f'betas: expected {nb} coefficients, got {betas_t.shape[1]}')
-        expr_t = dev_f32(expression, (expression.shape[0], -1)) if has_expr else None
-        if has_expr and expr_t.shape[1] != ne:
-            raise ValueError(f'expression: expected {ne} coefficients, got {expr_t.shape[1]}')
+        arena = torch.empty(n_co + B * n_pose * 9, dtype=torch.float32, device=device)
+        if betas is not None and betas.shape[-1] != nb and betas.numel() != betas.shape[0] * nb:
+            raise ValueError(f'betas: expected {nb} coefficients, got {betas.numel() // betas.shape[0]}')
+        if has_expr and expression.numel() != expression.shape[0] * ne:
+            raise ValueError(f'expression: expected {ne} coefficients, got {expression.numel() // expression.shape[0]}')
+        bp, bst = dev(betas, (nb,)) if betas is not None else (None, 0)
+        ep, est = dev(expression, (ne,)) if has_expr else (None, 0)
+        base = arena.data_ptr()
         _lib.check(lib.shapy_smplx_prepare_f32(
-            ptrs, cnts, len(given), _lib.ptr(betas_t), nb, _lib.ptr(expr_t), ne if has_expr else 0, NBpad,
-            _lib.ptr(full_pose) if n_pose else None, _lib.ptr(coeffs), _lib.ptr(coeffs_shape), B,
+            ptrs, cnts, strides, last + 1, bp, bst, nb, ep, est, ne if has_expr else 0, NBpad,
+            base + 4 * n_co if n_pose else None, base, base + 4 * B * NBpad if has_expr else None, B,
             _lib.current_stream()), 'shapy_smplx_prepare_f32')
-        out = self.forward_prepared(full_pose, coeffs, coeffs_shape=coeffs_shape, transl=transl,
-                                    get_skin=get_skin, return_shaped=return_shaped,
-                                    _shape_only=_shape_only)
+        out = self._run(dm, B, n_pose, base + 4 * n_co, base, base + 4 * B * NBpad if has_expr else None,
+                        None, transl, get_skin, return_shaped, _shape_only, (arena,))
         if return_full_pose and not _shape_only:
             J = dm['J']
-            out['full_pose'] = torch.cat([full_pose, eye(J - n_pose)], dim=1) if n_pose < J \
-                else full_pose
+            full_pose = arena[n_co:].view(B, n_pose, 3, 3)
+            if n_pose < J:
+                eye = torch.eye(3, dtype=torch.float32, device=device).view(1, 1, 3, 3).expand(B, J - n_pose, -1, -1)
+                out['full_pose'] = torch.cat([full_pose, eye], dim=1)
+            else:
+                out['full_pose'] = full_pose
         return out
 
     def forward_prepared(self, pose, coeffs, coeffs_shape=None, camera=None, transl=None,
@@ -339,21 +353,30 @@ class SMPLX(VersionedWeights, nn.Module):
                   returns ``proj_joints`` = softplus(c0) * (xy + c[1:3]) and ``cam_scale`` [B,1]
         ``shapy_head_prepare_f32`` produces pose / coeffs / camera for the regressor in one
         launch (HMRLikeRegressor.forward)."""
+        dm = self._device_model(self.shapedirs.device)
+        return self._run(dm, coeffs.shape[0], pose.shape[1], pose.data_ptr(), coeffs.data_ptr(),
+                         None if coeffs_shape is None else coeffs_shape.data_ptr(), camera, transl,
+                         get_skin, return_shaped, _shape_only, (pose, coeffs, coeffs_shape))
+
+    def _run(self, dm, B, n_pose, pose_ptr, coeffs_ptr, coeffs_shape_ptr, camera, transl, get_skin,
+             return_shaped, _shape_only, _keep):
+        """forward_prepared on raw device pointers (`_keep`: the tensors behind them)."""
         device = self.shapedirs.device
         lib = _lib.load()
         stream = _lib.current_stream()
-        dm = self._device_model(device)
         m = dm['struct']
         V, J = dm['V'], dm['J']
-        B, n_pose = coeffs.shape[0], pose.shape[1]
         f32 = dict(dtype=torch.float32, device=device)
+        has_cs = coeffs_shape_ptr is not None
         # ONE allocation for everything the layer writes and ONE C call for all its launches
         # (shapy_smplx_forward_f32): between ctypes calls the host used to lose ~40 us per layer
         n_out = J + m.n_static_lmk + (m.n_dyn_lmk if self.use_face_contour else 0)
         # the fused projection is only valid when nothing edits the joints afterwards
         fuse_cam = (camera is not None and not self.use_joint_regressor and transl is None
                     and not _shape_only)
-        sizes = [('v_shaped_full', (B, V, 3)), ('v_shaped', (B, V, 3) if coeffs_shape is not None else None)]
+        # (v_shaped directly behind v_shaped_full, no alignment gap: with adjacent coefficient rows the
+        # library then runs both shape GEMMs as one launch with M = 2 B)
+        sizes = [('v_shaped_pair', (2 * B, V, 3) if has_cs else (B, V, 3))]
         if not _shape_only:
             sizes += [('rot', (B, J, 3, 3)), ('pf', (B, dm['Ppad'])), ('A', (B, J, 12)),
                       ('posed', (B, J, 3)), ('dyn_row', (B,)), ('v_posed', (B, V, 3)),
@@ -371,30 +394,39 @@ class SMPLX(VersionedWeights, nn.Module):
             total += (n + 3) // 4 * 4                       # 16-byte aligned slices
         arena = torch.empty(total, **f32)
 
-        def view(name):
+        def view(name, skip=0):
             if name not in offs:
                 return None
             o, n, shp = offs[name]
-            return arena[o:o + n].view(shp)
-        bufs = {name: view(name) for name, _ in sizes}
-        dyn_row = bufs.get('dyn_row')
-        if dyn_row is not None:
-            dyn_row = dyn_row.view(torch.int32)
-        p = _lib.ptr
+            if skip:                                     # second half of the pair
+                shp = (shp[0] - skip,) + tuple(shp[1:])
+                o += skip * shp[1] * shp[2]
+            st, acc = [], 1
+            for d in reversed(shp):
+                st.append(acc)
+                acc *= d
+            return arena.as_strided(shp, st[::-1], o)     # one torch op per returned tensor
+        # raw pointers for everything the layer only uses internally (a torch view costs ~2 us of host
+        # time each and the call is host-bound); views only for what the caller gets back
+        base = arena.data_ptr()
+
+        def p(name):
+            return ctypes_vp()(base + 4 * offs[name][0]) if name in offs else None
+        pair_off = offs['v_shaped_pair'][0]
+        p_vsf = ctypes_vp()(base + 4 * pair_off)
+        p_vs = ctypes_vp()(base + 4 * (pair_off + B * V * 3)) if has_cs else None
         _lib.check(lib.shapy_smplx_forward_f32(
-            ctypes_byref(m), p(pose), _lib.POSE_ROTMAT, n_pose, p(coeffs), p(coeffs_shape), p(camera) if fuse_cam else None,
-            p(bufs['v_shaped_full']), p(bufs.get('v_shaped')), p(bufs.get('rot')), p(bufs.get('pf')),
-            p(bufs.get('A')), p(bufs.get('posed')), p(dyn_row), p(bufs.get('v_posed')),
-            p(bufs.get('vertices')), p(bufs.get('joints')), p(bufs.get('proj')), p(bufs.get('scale')),
+            ctypes_byref(m), pose_ptr, _lib.POSE_ROTMAT, n_pose, coeffs_ptr, coeffs_shape_ptr,
+            _lib.ptr(camera) if fuse_cam else None,
+            p_vsf, p_vs, p('rot'), p('pf'), p('A'), p('posed'), p('dyn_row'), p('v_posed'),
+            p('vertices'), p('joints'), p('proj'), p('scale'),
             B, int(self.use_face_contour), int(_shape_only), stream), 'shapy_smplx_forward_f32')
-        v_shaped_full = bufs['v_shaped_full']
-        v_shaped = v_shaped_full if coeffs_shape is None else bufs['v_shaped']
         output = defaultdict(lambda: None, faces=self.faces)
         if return_shaped:
-            output['v_shaped'] = v_shaped
+            output['v_shaped'] = view('v_shaped_pair', B if has_cs else 0)
         if _shape_only:
             return output
-        vertices, joints, proj, scale = bufs['vertices'], bufs['joints'], bufs.get('proj'), bufs.get('scale')
+        vertices, joints, proj, scale = view('vertices'), view('joints'), view('proj'), view('scale')
 
         if self.use_joint_regressor:
             Jn = self.extra_joint_regressor.shape[0]
@@ -433,3 +465,8 @@ def ctypes_vp():
 def ctypes_i32():
     import ctypes
     return ctypes.c_int32
+
+
+def ctypes_i64():
+    import ctypes
+    return ctypes.c_int64

@@ -631,15 +631,21 @@ def test_hrnet_grouped_branch_launches_equal_per_layer_launches(network, B, size
     """group_branches (the default): the convs at one depth of a module's parallel branches run as
     ONE persistent F(4x4) launch (csrc/conv_wino4g.hip, through shapy_hrnet_run's `group` ops)
     instead of one conv_wino4 launch per branch and stream -- same tasks, same arithmetic:
-    bit-identical features, at the headline batch too, eager and as a captured hipGraph."""
+    bit-identical features, at the headline batch too, eager and as a captured hipGraph.  (Per-layer
+    launches WITHOUT split-K: the persistent kernel has no split form, and a split layer adds its
+    partial sums in another association -- compared to rounding below.)"""
     from shapy_amd.utils import synthetic as syn
     bb = network.backbone
     keep = bb.group_branches, bb.multi_stream, bb.use_graph, bb.conv_algo, bb.wino4_min_hw
+    keep_split = bb.wino4_ksplit
     x = torch.from_numpy(syn.synthetic_images(B, size, 11)).cuda()
     try:
         bb.conv_algo, bb.wino4_min_hw = 'winograd4', 7
         bb.multi_stream, bb.use_graph = multi_stream, graph
         bb.group_branches = False
+        with torch.no_grad():
+            split = bb(x)['concat'].clone()              # the default plan: 384 @7x7 with S = 2
+        bb.wino4_ksplit = {}
         with torch.no_grad():
             ref = bb(x)['concat'].clone()
         bb.group_branches = True
@@ -653,7 +659,11 @@ def test_hrnet_grouped_branch_launches_equal_per_layer_launches(network, B, size
         assert sum(1 for o in plan.ops if o['group'] > 1) == (64 if size == 224 else 8)
     finally:
         bb.group_branches, bb.multi_stream, bb.use_graph, bb.conv_algo, bb.wino4_min_hw = keep
+        bb.wino4_ksplit = keep_split
     assert torch.equal(got, ref) and torch.equal(again, ref)
+    assert (split - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    if size == 224:
+        assert not torch.equal(split, ref)               # the split layers really ran
 
 
 @pytest.mark.parametrize('wino', [True, 4])
