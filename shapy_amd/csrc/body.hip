@@ -642,9 +642,12 @@ extern "C" int shapy_smplx_skin_f32(const ShapySmplxModel *m, const float *A, co
                                     float *vertices_out, int B, void *stream) {
   if (B <= 0) return SHAPY_OK;
   if (m->J > 64) return SHAPY_EINVAL;
-  // register block 4 vertices x 2 bodies once there are enough bodies to keep every CU busy with it
+  // register block 2 vertices x 2 bodies once there are enough bodies to keep every CU busy with it: 6 LDS
+  // reads per 24 packed FMAs (the two pipes level) and 2.6 waves per SIMD at B = 64 -- the 4 x 2 block has the
+  // same pipe balance but only 1.4 waves per SIMD, i.e. two rounds of a 10 us wave: 24.1 us
+  // (profiles/r05f_kernel_stats_smplx_b64.csv)
   if (B >= 16)
-    hipLaunchKernelGGL((smplx_skin_kernel<4, 2>), dim3((m->V + 1023) / 1024, (B + 1) / 2), dim3(256), 0,
+    hipLaunchKernelGGL((smplx_skin_kernel<2, 2>), dim3((m->V + 511) / 512, (B + 1) / 2), dim3(256), 0,
                        (hipStream_t)stream, m->lbs_weights_t, A, v_posed, vertices_out, m->V, m->J, B);
   else
     hipLaunchKernelGGL((smplx_skin_kernel<1, 1>), dim3((m->V + 255) / 256, B), dim3(256), 0,
