@@ -19,7 +19,7 @@
  *      batch_rodrigues (utils/rotation_utils.py:5-37), lbs() and batch_rigid_transform
  *      (models/body_models/lbs.py:99-196, :242-295), the landmark code (lbs.py:20-94),
  *      WeakPerspectiveCamera.forward (models/camera/camera_projection.py:181-213)
- *  shapy_mesh_to_mesh_f32 (+ _workspace_bytes)
+ *  shapy_mesh_to_mesh_f32 (+ _workspace_bytes), shapy_mesh_to_mesh_f64
  *      mesh_mesh_intersect_cuda.mesh_to_mesh_forward
  *      (mesh-mesh-intersection/src/mesh_mesh_intersect.cpp:36-64,
  *       src/mesh_mesh_intersect_cuda_op.cu:969-1079 and every kernel it launches)
@@ -352,19 +352,19 @@ int shapy_smplx_forward_f32(const ShapySmplxModel *model_host, const float *pose
  * (the reference's is BVH traversal order, unspecified).  Hits beyond max_coll are dropped
  * and counted in *overflow_out (int32 device counter, may be NULL); the reference writes
  * out of bounds in that case (.cu:551,565).
- * float32 ONLY -- a deliberate refusal, not an omission: the reference instantiates the operator
- * for double as well (AT_DISPATCH_FLOATING_TYPES, .cu:996), but no caller in SHAPY ever passes
- * float64 triangles (body_measurements.py:137-139 feeds float32 v_shaped), its predicates mix
- * float constants into the double instantiation (FLT_EPSILON / fabsf in CMP, .cu:91-92; the
- * 1e-4 determinant cut), so a float64 port would have to reproduce float-in-double quirks that
- * nothing pins.  The Python operator raises NotImplementedError for float64 tensors
- * (shapy_amd/measurements/mesh_mesh_intersection.py); callers holding float64 meshes convert
- * with .float() exactly as BodyMeasurements' own inputs are.
+ * shapy_mesh_to_mesh_f64 is the reference's second instantiation (AT_DISPATCH_FLOATING_TYPES, .cu:996) on
+ * float64 triangles: the same observable semantics, double arithmetic with the float constants the reference
+ * keeps in it (CMP converts to float and compares against FLT_EPSILON, .cu:91-92; the 1e-4 determinant cut);
+ * bcs_out is float64.  No SHAPY caller passes float64, so it is the brute-force scan for every Q (no
+ * workspace): slow for large query meshes, correct for all; bit-exact against the oracle's float64 build.
  * ------------------------------------------------------------------------------------- */
 size_t shapy_mesh_to_mesh_workspace_bytes(int B, int Q, int F, int max_coll);
 int shapy_mesh_to_mesh_f32(const float *query, const float *target, int B, int Q, int F,
                            int max_coll, int64_t *faces_out, float *bcs_out, void *workspace,
                            size_t workspace_bytes, int32_t *overflow_out, void *stream);
+int shapy_mesh_to_mesh_f64(const double *query, const double *target, int B, int Q, int F,
+                           int max_coll, int64_t *faces_out, double *bcs_out, int32_t *overflow_out,
+                           void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused virtual measurements: mass, height, chest, waist, hips from v_shaped + faces.

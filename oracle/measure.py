@@ -25,8 +25,8 @@ f32 = np.float32
 
 def build(force=False):
     so = osp.join(_HERE, '_build', 'liboracle.so')
-    src = osp.join(_HERE, 'mesh_intersect.c')
-    if force or not osp.exists(so) or osp.getmtime(so) < osp.getmtime(src):
+    srcs = [osp.join(_HERE, f) for f in ('mesh_intersect.c', 'mesh_intersect_f64.c', 'Makefile')]
+    if force or not osp.exists(so) or osp.getmtime(so) < max(osp.getmtime(f) for f in srcs):
         subprocess.check_call(['make', '-C', _HERE, '-s', '-B' if force else '-s'])
     return so
 
@@ -44,6 +44,11 @@ def lib():
         L.shapy_oracle_tri_tri_sat.argtypes = [fp, fp]
         L.shapy_oracle_tri_tri_point.restype = ctypes.c_int
         L.shapy_oracle_tri_tri_point.argtypes = [fp, fp, fp]
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.shapy_oracle_mesh_to_mesh_f64.restype = ctypes.c_long
+        L.shapy_oracle_mesh_to_mesh_f64.argtypes = [
+            dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+            ctypes.POINTER(ctypes.c_int64), dp]
         _LIB = L
     return _LIB
 
@@ -65,6 +70,23 @@ def mesh_to_mesh_forward(query, target, max_collisions=16):
         _fp(query), _fp(target), B, Q, F, max_collisions,
         faces.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _fp(bcs))
     mesh_to_mesh_forward.last_dropped = int(dropped)
+    return faces, bcs
+
+
+def mesh_to_mesh_forward_f64(query, target, max_collisions=16):
+    """The reference's double instantiation (mesh_mesh_intersect_cuda_op.cu:996): float64 triangles ->
+    (faces int64 [B,Q*MC], bcs f64 [B,Q*MC,2,3]); CMP keeps its float conversion and FLT_EPSILON."""
+    query = np.ascontiguousarray(query, np.float64)
+    target = np.ascontiguousarray(target, np.float64)
+    B, Q = query.shape[:2]
+    F = target.shape[1]
+    faces = np.empty((B, Q * max_collisions), np.int64)
+    bcs = np.empty((B, Q * max_collisions, 2, 3), np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    dropped = lib().shapy_oracle_mesh_to_mesh_f64(
+        query.ctypes.data_as(dp), target.ctypes.data_as(dp), B, Q, F, max_collisions,
+        faces.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), bcs.ctypes.data_as(dp))
+    mesh_to_mesh_forward_f64.last_dropped = int(dropped)
     return faces, bcs
 
 

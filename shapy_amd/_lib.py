@@ -137,6 +137,8 @@ SIGNATURES = {
     'shapy_mesh_to_mesh_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 4),
     'shapy_mesh_to_mesh_f32': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, vp, vp, vp, ctypes.c_size_t, vp, vp]),
+    'shapy_mesh_to_mesh_f64': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, vp, vp, vp, vp]),
     'shapy_body_measure_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int] * 3),
     'shapy_body_measure_f32': (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               c_i32_p, c_float_p, ctypes.c_int, vp, vp,

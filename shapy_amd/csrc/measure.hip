@@ -29,8 +29,9 @@ namespace shapy {
 
 constexpr int SCAN_THREADS = 256;
 
-__device__ __forceinline__ Tri load_tri(const float *p) {
-  Tri t;
+template <typename T>
+__device__ __forceinline__ TriT<T> load_tri(const T *p) {
+  TriT<T> t;
   t.v0 = v3(p[0], p[1], p[2]);
   t.v1 = v3(p[3], p[4], p[5]);
   t.v2 = v3(p[6], p[7], p[8]);
@@ -55,20 +56,22 @@ __device__ __forceinline__ int block_rank(bool flag, int &total, int *wave_cnt) 
   return off + below;
 }
 
+// T = float: every SHAPY call; T = double: the reference's second instantiation (shapy_mesh_to_mesh_f64)
+template <typename T>
 __global__ __launch_bounds__(SCAN_THREADS) void mesh_to_mesh_scan_kernel(
-    const float *__restrict__ query, const float *__restrict__ target, int Q, int F, int MC,
-    long long *__restrict__ faces_out, float *__restrict__ bcs_out, int *__restrict__ overflow) {
+    const T *__restrict__ query, const T *__restrict__ target, int Q, int F, int MC,
+    long long *__restrict__ faces_out, T *__restrict__ bcs_out, int *__restrict__ overflow) {
   __shared__ int wave_cnt[SCAN_THREADS / 64];
   const int q = blockIdx.x, b = blockIdx.y;
-  const Tri qt = load_tri(query + ((long)b * Q + q) * 9);
-  const float *tb = target + (long)b * F * 9;
+  const TriT<T> qt = load_tri(query + ((long)b * Q + q) * 9);
+  const T *tb = target + (long)b * F * 9;
   long long *fo = faces_out + ((long)b * Q + q) * MC;
-  float *bo = bcs_out + ((long)b * Q + q) * MC * 6;
+  T *bo = bcs_out + ((long)b * Q + q) * MC * 6;
   int base = 0;
   for (int f0 = 0; f0 < F; f0 += SCAN_THREADS) {
     const int f = f0 + threadIdx.x;
     bool hit = false;
-    Tri tt;
+    TriT<T> tt;
     if (f < F) {
       tt = load_tri(tb + (long)f * 9);
       hit = aabb_overlap(qt, tt) && tri_tri_sat(qt, tt);
@@ -77,11 +80,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void mesh_to_mesh_scan_kernel(
     const int slot = base + block_rank(hit, total, wave_cnt);
     if (hit) {
       if (slot < MC) {
-        V3 bc;
+        V3T<T> bc;
         const bool ok = tri_tri_point(qt, tt, bc);
         fo[slot] = f;
         if (ok) {
-          float *o = bo + (long)slot * 6;
+          T *o = bo + (long)slot * 6;
           o[0] = bc.x; o[1] = bc.y; o[2] = bc.z;
           o[3] = bc.x; o[4] = bc.y; o[5] = bc.z;
         }
@@ -562,13 +565,36 @@ extern "C" int shapy_mesh_to_mesh_f32(const float *query, const float *target, i
   if (overflow_out) SHAPY_HIP_TRY(hipMemsetAsync(overflow_out, 0, sizeof(int32_t), s));
   if (F == 0) return SHAPY_OK;
   if (Q <= SCAN_MAX_Q) {
-    hipLaunchKernelGGL(mesh_to_mesh_scan_kernel, dim3(Q, B), dim3(SCAN_THREADS), 0, s, query, target,
+    hipLaunchKernelGGL(mesh_to_mesh_scan_kernel<float>, dim3(Q, B), dim3(SCAN_THREADS), 0, s, query, target,
                        Q, F, max_coll, (long long *)faces_out, bcs_out, overflow_out);
     return (int)hipGetLastError();
   }
   if (workspace_bytes < mesh_to_mesh_bvh_workspace(B, Q, F, max_coll)) return SHAPY_EWORKSPACE;
   return mesh_to_mesh_bvh(query, target, B, Q, F, max_coll, (long long *)faces_out, bcs_out,
                           workspace, workspace_bytes, overflow_out, s);
+}
+
+// The reference's double instantiation (mesh_mesh_intersect_cuda_op.cu:996, AT_DISPATCH_FLOATING_TYPES): same
+// observable semantics on float64 triangles -- the predicates keep their float constants (CMP converts to float,
+// FLT_EPSILON; the 1e-4 determinant cut), everything else is double arithmetic.  No SHAPY caller passes float64,
+// so this is the plain brute-force form for every Q: one workgroup per (mesh, query triangle) scans the targets
+// in index order.  Slow for large query meshes (Q x F pair tests per mesh; the float32 operator switches to the
+// LBVH there), correct for all.
+extern "C" int shapy_mesh_to_mesh_f64(const double *query, const double *target, int B, int Q, int F,
+                                      int max_coll, int64_t *faces_out, double *bcs_out,
+                                      int32_t *overflow_out, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (B < 0 || Q < 0 || F < 0 || max_coll <= 0) return SHAPY_EINVAL;
+  const size_t nslots = (size_t)B * Q * max_coll;
+  if (nslots == 0) return SHAPY_OK;
+  if (Q > 65535 || B > 65535) return SHAPY_EINVAL;                 // grid (Q, B)
+  SHAPY_HIP_TRY(hipMemsetAsync(faces_out, 0xFF, nslots * sizeof(int64_t), s));   // -1
+  SHAPY_HIP_TRY(hipMemsetAsync(bcs_out, 0, nslots * 6 * sizeof(double), s));
+  if (overflow_out) SHAPY_HIP_TRY(hipMemsetAsync(overflow_out, 0, sizeof(int32_t), s));
+  if (F == 0) return SHAPY_OK;
+  hipLaunchKernelGGL(mesh_to_mesh_scan_kernel<double>, dim3(Q, B), dim3(SCAN_THREADS), 0, s, query, target,
+                     Q, F, max_coll, (long long *)faces_out, bcs_out, overflow_out);
+  return (int)hipGetLastError();
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

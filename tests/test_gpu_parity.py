@@ -1100,6 +1100,46 @@ def test_mesh_to_mesh_operator_bit_exact_vs_oracle():
     assert (e[0] == -1).all() and (e[1] == 0).all()
 
 
+def test_mesh_to_mesh_operator_float64_bit_exact_vs_oracle():
+    """The reference's second instantiation (AT_DISPATCH_FLOATING_TYPES, mesh_mesh_intersect_cuda_op.cu:996):
+    float64 triangles through shapy_mesh_to_mesh_f64 -- faces and float64 barycentrics bit-equal to the
+    oracle's float64 build (same float constants inside: CMP in float, the 1e-4 cut), plane quads and
+    arbitrary query triangles, overflow, mixed dtypes refused."""
+    _need_gpu()
+    import mesh_mesh_intersect_cuda
+    from oracle import measure as om
+    from shapy_amd.utils import synthetic as syn
+    faces, meshes = syn.load_topology()
+    tris = np.ascontiguousarray(meshes[:, faces]).astype(np.float64)    # 4,F,3,3
+    tris += 1e-9 * np.random.default_rng(3).standard_normal(tris.shape)  # genuinely float64 coordinates
+    q = om.plane_triangles(np.array([-0.0343, -0.2515, -0.4845, 0.2], np.float32)).astype(np.float64)
+    q2 = np.ascontiguousarray(np.concatenate([q, tris[::-1][:, 5000:5030]], axis=1))       # Q = 32
+    for query, mc in ((q, 256), (q2, 64), (q, 16)):
+        f_ref, b_ref = om.mesh_to_mesh_forward_f64(query, tris, mc)
+        f, b = mesh_mesh_intersect_cuda.mesh_to_mesh_forward(
+            torch.from_numpy(query).cuda(), torch.from_numpy(tris).cuda(), max_collisions=mc)
+        torch.cuda.synchronize()
+        assert f.dtype == torch.int64 and b.dtype == torch.float64
+        assert b.shape == (4, query.shape[1] * mc, 2, 3)
+        assert np.array_equal(f.cpu().numpy(), f_ref)
+        assert np.array_equal(b.cpu().numpy(), b_ref)
+        assert int(mesh_mesh_intersect_cuda.mesh_to_mesh_forward.last_overflow.item()) == \
+            om.mesh_to_mesh_forward_f64.last_dropped
+        assert (f_ref >= 0).sum() > 100
+    # next to the float32 operator on the same (rounded) triangles: the same faces, barycentrics to rounding
+    f32 = mesh_mesh_intersect_cuda.mesh_to_mesh_forward(
+        torch.from_numpy(q.astype(np.float32)).cuda(), torch.from_numpy(tris.astype(np.float32)).cuda(),
+        max_collisions=256)
+    f64 = mesh_mesh_intersect_cuda.mesh_to_mesh_forward(
+        torch.from_numpy(q).cuda(), torch.from_numpy(tris).cuda(), max_collisions=256)
+    same = (f32[0] == f64[0])
+    assert same.float().mean().item() > 0.99
+    assert (f32[1].double() - f64[1])[same].abs().max().item() < 1e-4
+    with pytest.raises(NotImplementedError):
+        mesh_mesh_intersect_cuda.mesh_to_mesh_forward(
+            torch.from_numpy(q.astype(np.float32)).cuda(), torch.from_numpy(tris).cuda())
+
+
 def test_mesh_to_mesh_bvh_large_target_fallback_paths_vs_oracle():
     """Targets beyond what the LBVH build keeps in LDS (SMPL-X: sorted keys as (Morton, face16) and
     the refit's ready lists fit 128 KB up to ~21,800 / ~26,000 triangles): two bodies side by side

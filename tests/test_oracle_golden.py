@@ -183,3 +183,25 @@ def test_full_regressor_oracle_matches_reference(golden_dir, hrnet_sd, synth_smp
     m = measure.body_measurements(last['v_shaped'][:, faces], LM)
     for k in ('mass', 'height', 'chest', 'waist', 'hips'):
         np.testing.assert_allclose(m[k], g['meas_' + k], rtol=1e-4, atol=1e-4, err_msg=k)
+
+
+def test_oracle_float64_instantiation_of_the_intersection_operator():
+    """oracle/mesh_intersect.c compiled with REAL = double (the reference dispatches on the floating type,
+    mesh_mesh_intersect_cuda_op.cu:996): on float32-representable triangles it reports the same hit set as
+    the float32 build (the predicates' tolerances are float in both) with barycentrics equal to rounding,
+    and reproduces the shipped sample's circumferences through the same consumer."""
+    from oracle import measure as om
+    from shapy_amd.utils import synthetic as syn
+    faces, meshes = syn.load_topology()
+    tris = np.ascontiguousarray(meshes[:2, faces])
+    q = om.plane_triangles(np.array([-0.0343, -0.2515], np.float32))
+    f32f, f32b = om.mesh_to_mesh_forward(q, tris, 256)
+    f64f, f64b = om.mesh_to_mesh_forward_f64(q, tris, 256)
+    assert f64b.dtype == np.float64 and (f32f >= 0).sum() > 150
+    same = (f32f == f64f)
+    assert same.mean() > 0.99
+    assert np.abs(f32b.astype(np.float64) - f64b)[same].max() < 1e-4
+    # overflow accounting is the same rule
+    om.mesh_to_mesh_forward(q, tris, 16)
+    om.mesh_to_mesh_forward_f64(q, tris, 16)
+    assert om.mesh_to_mesh_forward.last_dropped == om.mesh_to_mesh_forward_f64.last_dropped > 0
