@@ -809,7 +809,7 @@ def run_regressor(args, rank, world, local_rank):
                    'global_batch': world * B, 'parallelism': f'dp{world}',
                    'multi_stream': not args.single_stream, 'conv_algo': algo,
                    'd2h_betas_in_timed_region': True,
-                   'wino4_ksplit': {f'{c}@{t}': sl for (c, t), sl in net.backbone.wino4_ksplit.items()},
+                   'wino4_ksplit': {f'{c}@{t}': sl for (c, t), sl in net.backbone.ksplit_policy(B).items()},
                    'hip_graph': bool(net.backbone.use_graph is True or
                                      (net.backbone.use_graph == 'auto' and
                                       B <= net.backbone.graph_max_batch))},

@@ -328,11 +328,14 @@ int conv2d_wino4(ConvK k, hipStream_t s) {
   } else if (S == 2) {
     if (cps == 12) W4_LAUNCH(12, 3, 2);
     else if (cps == 6) W4_LAUNCH(6, 3, 2);
+    else if (cps == 3) W4_LAUNCH(3, 3, 2);
     else W4_LAUNCH(0, 3, 2);
   } else if (S == 3 && cps == 8) {
     W4_LAUNCH(8, 3, 3);
   } else if (S == 4 && cps == 6) {
     W4_LAUNCH(6, 3, 4);
+  } else if (S == 4 && cps == 3) {
+    W4_LAUNCH(3, 3, 4);
   } else {
     return SHAPY_EINVAL;
   }

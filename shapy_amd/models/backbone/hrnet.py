@@ -35,8 +35,17 @@ BN_MOMENTUM = 0.1
 #: product defaults of HighResolutionNet.conv_algo / .wino4_min_hw (see there)
 DEFAULT_CONV_ALGO = 'winograd4'
 DEFAULT_WINO4_MIN_HW = 7
-#: F(4x4) split-K (csrc/conv_wino4.hip): {(Cin, most 4x4 tiles per image): K slices}
-DEFAULT_WINO4_KSPLIT = {(384, 4): 2}
+#: F(4x4) split-K (csrc/conv_wino4.hip) by batch bucket: (largest batch of the bucket | None, {(Cin, most 4x4
+#: tiles per image): K slices}).  Measured on MI355X, backbone ms at B = 1 / 8 / 32 / 64
+#: (profiles/r05h_ksplit_latency_sweep.txt): no split 5.22 / 5.87 / 7.90 / 12.42; the three policies below
+#: 3.61 / 4.09 / 7.14 / 12.39 -- small batches are chains of latency-bound launches whose length is the K
+#: depth of a layer, large ones are throughput-bound and lose with every extra prologue / epilogue.
+DEFAULT_WINO4_KSPLIT_BY_BATCH = (
+    (8, {(384, 4): 4, (192, 16): 4, (96, 49): 2}),
+    (32, {(384, 4): 4, (192, 16): 2}),
+    (None, {(384, 4): 2}),
+)
+DEFAULT_WINO4_KSPLIT = DEFAULT_WINO4_KSPLIT_BY_BATCH[-1][1]        # the headline batch's policy
 
 
 # ------------------------------------------------------------------------------------------
@@ -246,17 +255,21 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.wino4_n64 = tuple(int(c) for c in os.environ.get('SHAPY_WINO4_N64', '').split(',') if c)
         #: F(4x4) split-K: {(Cin, most 4x4 tiles per image): S} -- a layer with that many input channels
         #: on a map of at most that many tiles runs S workgroups per output tile, each over Cin / S
-        #: channels (csrc/conv_wino4.hip).  For the K-deep layers on the small maps: 384 -> 384 @7x7 is
-        #: 128 workgroups of 24 chunks at B = 64.  The choice depends on the layer alone, never on the
-        #: batch: features stay bit-identical across batch sizes.  (SHAPY_W4_KSPLIT="384@4:2,192@16:2"
-        #: overrides it for A/B runs; "" = no split anywhere.)
-        self.wino4_ksplit = dict(DEFAULT_WINO4_KSPLIT)
+        #: channels (csrc/conv_wino4.hip).  The policy is chosen per BATCH BUCKET (wino4_ksplit_by_batch:
+        #: B <= 8, B <= 32, larger), each bucket with a plan of its own: inside a bucket the features are
+        #: bit-identical from batch size to batch size, between buckets the split layers differ by
+        #: float32 rounding (another association of the same sums), as any algorithm choice by shape does.
+        #: wino4_ksplit = a dict: that policy at every batch size (tests, A/B runs); None = by bucket.
+        #: (SHAPY_W4_KSPLIT="384@4:2,192@16:2" sets such a dict; "" = no split anywhere.)
+        self.wino4_ksplit_by_batch = tuple((b, dict(p)) for b, p in DEFAULT_WINO4_KSPLIT_BY_BATCH)
+        self.wino4_ksplit = None
         if 'SHAPY_W4_KSPLIT' in os.environ:
             self.wino4_ksplit = {}
             for item in filter(None, os.environ['SHAPY_W4_KSPLIT'].split(',')):
                 key, sl = item.split(':')
                 cin, tmax = key.split('@')
                 self.wino4_ksplit[(int(cin), int(tmax))] = int(sl)
+        self._ksplit_eff = None          # the policy of the plan being built (None: the largest bucket's)
 
         #: conv_algo='winograd4': the convs at the same depth of a HighResolutionModule's parallel
         #: branches as ONE persistent grouped launch (csrc/conv_wino4g.hip) instead of one launch
@@ -424,11 +437,21 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         return (self.conv_algo == 'winograd4' and min(Hi, Wi) >= self.wino4_min_hw
                 and winograd.eligible4(ks, st, pad, cin, cout, ups))
 
+    def ksplit_policy(self, B=None):
+        """The split-K policy of a forward with batch size B (None: the largest bucket's)."""
+        if self.wino4_ksplit is not None:
+            return self.wino4_ksplit
+        for max_b, pol in self.wino4_ksplit_by_batch:
+            if max_b is None or (B is not None and B <= max_b):
+                return pol
+        return self.wino4_ksplit_by_batch[-1][1]
+
     def _ksplit(self, cin, Hi, Wi):
-        """K slices of an F(4x4) layer (``wino4_ksplit``); 1 = no split."""
+        """K slices of an F(4x4) layer under the policy of the plan being built; 1 = no split."""
         t = ((Hi + 3) // 4) * ((Wi + 3) // 4)
         best = 1
-        for (c, tmax), sl in self.wino4_ksplit.items():
+        pol = self._ksplit_eff if self._ksplit_eff is not None else self.ksplit_policy(None)
+        for (c, tmax), sl in pol.items():
             if c == cin and t <= tmax and (cin // 16) % sl == 0:
                 best = max(best, int(sl))
         return best
@@ -685,7 +708,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
              res_ld=0, res_coff=0, relu=0, ups=1, tile=0, wgt_off=-1, bias_off=-1, wino_off=-1)
         return P
 
-    def _compile(self, H, W, device, graph=False):
+    def _compile(self, H, W, device, graph=False, B=None):
         # event-driven plan: eager multi-stream forwards only (capturing it into a hipGraph segfaults
         # inside graph creation on ROCm 7.2; the captured plan keeps the barrier form)
         self._dag_eff = bool(self.dag and self.multi_stream and not graph)
@@ -696,14 +719,20 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         if ver != self._engine_ver:          # a parameter / buffer was edited in place
             self._engine = {}
             self._engine_ver = ver
-        key = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
-               self.wino4_min_hw, self._group_on(), self._dag_eff, tuple(self.wino4_n64),
-               tuple(sorted(self.wino4_ksplit.items())), tuple(sorted(self.layer_algo.items())),
-               self.tile_flags, tuple(sorted(self.tile_overrides.items())))
+        pol = self.ksplit_policy(B) if self.compute_dtype == 'f32' else {}
+        key_w = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
+                 self.wino4_min_hw, self._group_on(), self._dag_eff, tuple(self.wino4_n64),
+                 tuple(sorted(self.layer_algo.items())), self.tile_flags,
+                 tuple(sorted(self.tile_overrides.items())))
+        key = key_w + (tuple(sorted(pol.items())),)
         eng = self._engine.get(key)
         if eng is not None:
             return eng
-        P = self._build_plan(H, W, bf16, self.compute_dtype == 'f32x6')
+        self._ksplit_eff = pol
+        try:
+            P = self._build_plan(H, W, bf16, self.compute_dtype == 'f32x6')
+        finally:
+            self._ksplit_eff = None
         P.sync_plan()
         ws_per_img = P.allocate()
         n = len(P.ops)
@@ -721,8 +750,13 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             a.res_off = -1 if o['resb'] is None else o['resb'].off
             a.split_off = -1 if o.get('scrb') is None else o['scrb'].off
             a.cnt_off = int(o.get('cnt_off', -1))
-        blob = np.frombuffer(b''.join(P.wchunks), dtype=np.uint8)
-        weights = torch.from_numpy(blob.copy()).to(device)
+        # the weight blob does not depend on the split policy (same layers, same order, same transforms):
+        # plans that differ in nothing else share ONE device copy (1.3 GB with the default algorithm)
+        weights = next((e['weights'] for k, e in self._engine.items()
+                        if k[:-1] == key_w and e['weights'].numel() == P.wbytes), None)
+        if weights is None:
+            blob = np.frombuffer(b''.join(P.wchunks), dtype=np.uint8)
+            weights = torch.from_numpy(blob.copy()).to(device)
         eng = dict(ops=arr, n_ops=n, weights=weights, ws_per_img=ws_per_img, cnt_per_img=P.cnt_ints,
                    plan=P, ws=None, graphs={},
                    feat_dim=P.ops[-1]['Cin'], esz=2 if bf16 else 4,
@@ -766,7 +800,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             for _ in range(3):
                 # the product's own engine (same plan key): the pass below runs its ops one at a
                 # time on the caller's stream, whatever lanes / groups / events the plan carries
-                eng = self._compile(H, W, x.device, graph=graph)
+                eng = self._compile(H, W, x.device, graph=graph, B=B)
                 layers = self._calibrate_pass(lib, eng, x)
                 worst = {}
                 for name, algo, e_rms, e_max in layers:
@@ -903,7 +937,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 self.calibrate(self._guard_probe(x), graph=use_graph)
             elif recheck:
                 self.calibrate(x[:min(B, 2)], graph=use_graph)     # only ever ADDS demotions
-        eng = self._compile(H, W, x.device, graph=use_graph)
+        eng = self._compile(H, W, x.device, graph=use_graph, B=B)
         if use_graph:
             return {'concat': self._forward_graph(lib, eng, x)}
         need = eng['ws_per_img'] * B * eng['esz']

@@ -227,6 +227,8 @@ WINO4_SPLIT_CASES = [
     (1, 7, 7, 384, 384, True, True, 2),        # 4 of 16 tiles live (dead lanes never touch the slab)
     (3, 7, 9, 96, 96, True, False, 2),         # partial edge tiles, generic chunk loop (3 chunks per slice)
     (64, 14, 14, 192, 192, True, True, 2),     # the 14x14 branch: KC = 6
+    (8, 14, 14, 192, 192, True, True, 4),      # ... small-batch policy: KC = 3, four slices
+    (8, 28, 28, 96, 96, True, True, 2),        # the 28x28 branch, small-batch policy: KC = 3, two slices
     (5, 7, 7, 512, 512, False, True, 2),       # 64-channel N tile (four multiplying waves), 16 chunks per slice
     (5, 7, 7, 512, 512, True, True, 4),
 ]

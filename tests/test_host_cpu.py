@@ -141,6 +141,7 @@ def _executor_order(ops):
 
 @pytest.mark.parametrize('dag,group,ksplit', [(True, False, {}), (True, False, {(384, 4): 2}),
                                               (True, False, {(384, 4): 4, (192, 16): 2}),
+                                              (True, False, {(384, 4): 4, (192, 16): 4, (96, 49): 2}),
                                               (False, False, {(384, 4): 2}), (False, True, {(384, 4): 2})])
 def test_plan_orders_every_memory_hazard(hrnet, dag, group, ksplit):
     """The executor's order (lanes, barriers, dependency events, launch groups) covers every hazard
@@ -160,8 +161,9 @@ def test_plan_orders_every_memory_hazard(hrnet, dag, group, ksplit):
         hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw, hrnet.wino4_ksplit = keep
     n_split = sum(1 for o in P.ops if o.get('scrb') is not None)
     # 384 -> 384 @7x7: 3 modules x 8 convs, 192 -> 192 @14x14: 7 modules x 8; none inside launch groups
-    assert n_split == (0 if not ksplit else 0 if group else 24 + (56 if (192, 16) in ksplit else 0))
-    cnts = sorted((o['cnt_off'], _lib.w4_split_sizes(o['Hi'], o['Wi'], o['Cout'], 2)[1])
+    assert n_split == (0 if not ksplit else 0 if group else
+                       24 + (56 if (192, 16) in ksplit else 0) + (64 if (96, 49) in ksplit else 0))
+    cnts = sorted((o['cnt_off'], _lib.w4_split_sizes(o['Hi'], o['Wi'], o['Cout'], 2)[1])   # (independent of S)
                   for o in P.ops if o.get('scrb') is not None)
     assert all(c0 + n <= c1 for (c0, n), (c1, _) in zip(cnts, cnts[1:]))      # disjoint counter slices
     assert not cnts or cnts[-1][0] + cnts[-1][1] == P.cnt_ints
@@ -402,6 +404,26 @@ def test_split_k_policy_marks_the_7x7_branch_and_nothing_else(hrnet):
         assert all((o['tile'] >> 21) & 3 == 1 and o['tile'] & _lib.TILE_WINO4 for o in split)
         assert all(o['scrb'].size == 2 * 4 * 16 * 384 for o in split)
         assert P.cnt_ints == 24 * 2 * 24
+    # by batch bucket when no override is set: more slices (and the 14x14 / 28x28 branches) for small batches
+    assert keep[1] is None or isinstance(keep[1], dict)
+    hrnet.wino4_ksplit = None
+    try:
+        assert hrnet.ksplit_policy(64) == hrnet.ksplit_policy(None) == hrnet.ksplit_policy(33) == {(384, 4): 2}
+        assert hrnet.ksplit_policy(32) == hrnet.ksplit_policy(9) == {(384, 4): 4, (192, 16): 2}
+        assert hrnet.ksplit_policy(8) == hrnet.ksplit_policy(1) == {(384, 4): 4, (192, 16): 4, (96, 49): 2}
+        hrnet.conv_algo = 'winograd4'
+        hrnet._ksplit_eff = hrnet.ksplit_policy(1)
+        Ps = hrnet._build_plan(224, 224)
+    finally:
+        hrnet._ksplit_eff = None
+        hrnet.conv_algo, hrnet.wino4_ksplit = keep
+    by_s = {}
+    for o in Ps.ops:
+        sl = ((o['tile'] >> 21) & 3) + 1 if o['type'] == 0 else 1
+        if sl > 1:
+            by_s[(o['Cin'], o['Hi'], sl)] = by_s.get((o['Cin'], o['Hi'], sl), 0) + 1
+    # 24 convs @7x7 in four slices, 56 @14x14 in four, 64 @28x28 in two (4 tiles x 49 = 49 tiles per image)
+    assert by_s == {(384, 7, 4): 24, (192, 14, 4): 56, (96, 28, 2): 64}
     assert _lib.w4_split_sizes(7, 7, 384, 2) == (2 * 4 * 16 * 384, 48)
     assert _lib.w4_split_sizes(14, 14, 192, 2) == (2 * 16 * 16 * 192, 24)
     with pytest.raises(ValueError):
