@@ -46,6 +46,7 @@ struct ConvK {
   int no_allk;                  // tuning: Winograd K loop always chunk by chunk
   int flat;                     // bf16, Cin % 32 != 0: flat-K kernel
   int pd3;                      // implicit GEMM: three chunks of global loads in flight
+  int ups_split;                // upsample-scatter layers: workgroups per tile, each scatters ups / ups_split rows
   int ksplit;                   // F(4x4): K slices per output tile (SHAPY_TILE_W4_KSPLIT), 1 = none
   void *split_ws;               // ... their slab (ShapyConv.split_ws) and its size (conv2d_wino4)
   unsigned split_bytes;
@@ -226,9 +227,12 @@ struct VecIO<BF16> {
   }
 };
 
+// dy0 .. dy1: the rows of a value's UPS x UPS block this workgroup scatters (all of them unless the launch
+// runs several workgroups per tile, ConvK.ups_split)
 template <typename T, int TM, int TN, int UPS>
 __device__ __forceinline__ void conv_epilogue_vec(const ConvK &p, f32x4 (&acc)[TM][TN],
-                                                  char *lds_wave, int row0, int col0, int lane) {
+                                                  char *lds_wave, int row0, int col0, int lane,
+                                                  int dy0 = 0, int dy1 = UPS) {
   constexpr int CG = VecIO<T>::CG;
   constexpr int R = 16 * TM, C = 16 * TN, LDC = C + 4, NG = C / CG;
   static_assert(C % CG == 0, "wave tile width is a multiple of the channel group");
@@ -270,8 +274,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvK &p, f32x4 (&acc)[T
       pix0 = ((long)(b * p.Ho + ho) * UPS) * WoU + (long)wo * UPS;
     }
     if (col + CG - 1 < p.Cout) {
-#pragma unroll
-      for (int dy = 0; dy < UPS; ++dy) {
+      for (int dy = dy0; dy < dy1; ++dy) {
         float rv[UPS][CG];
 #pragma unroll
         for (int dx = 0; dx < UPS; ++dx) {
@@ -294,7 +297,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvK &p, f32x4 (&acc)[T
         }
       }
     } else {
-      for (int dy = 0; dy < UPS; ++dy)
+      for (int dy = dy0; dy < dy1; ++dy)
         for (int dx = 0; dx < UPS; ++dx)
           for (int e = 0; e < CG && col + e < p.Cout; ++e) {
             const long pi = pix0 + (long)dy * WoU + dx;

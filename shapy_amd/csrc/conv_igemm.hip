@@ -52,7 +52,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int wg = conv_tile_index(p);
+  // upsample-scatter layers run p.ups_split workgroups per tile (neighbours in dispatch order): each
+  // computes the tile's (tiny) GEMM and scatters its share of the UPS rows of every value's block
+  int wg = conv_tile_index(p);
+  int dy0 = 0, dy1 = UPS;
+  if constexpr (UPS > 1) {
+    const int G = p.ups_split;
+    const int part = wg % G;
+    wg /= G;
+    dy0 = part * (UPS / G);
+    dy1 = dy0 + UPS / G;
+  }
   const int m_blk = (wg / p.nbx) * BM, n_blk = (wg % p.nbx) * BN;
   const int kq = t % KQ, lrow = t / KQ;
 
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   if constexpr (VEC) {
     if (p.vec4) {
       conv_epilogue_vec<T, TM, TN, UPS>(p, acc, lds + wave * (LDS_EPI / 4), m_blk + wm * (BM / WM),
-                                n_blk + wn * (BN / WN), lane);
+                                        n_blk + wn * (BN / WN), lane, dy0, dy1);
       return;
     }
   }
@@ -232,6 +242,15 @@ template <typename T, int BM, int BN, int WM, int WN, int UPS = 1, int KQ = 4>
 static int launch(ConvK k, hipStream_t s) {
   k.nbx = (k.Cout + BN - 1) / BN;
   k.nby = (k.M + BM - 1) / BM;
+  // The scatter of a conv1x1 + nearest-Upsample(UPS) + add layer re-reads and re-writes UPS x UPS output
+  // pixels per computed value from the FEW workgroups of a low-resolution GEMM (25 for the 7x7 source at
+  // B = 32: 76 us for the x8 layer in bf16, on the lane that closes a stage-4 module,
+  // profiles/r05j_timeline_bf16_b32_verbose.txt): UPS workgroups per tile, one output row of every block
+  // each.  The GEMM is recomputed (K <= 384: nothing); vector epilogue only (the scalar form keeps one).
+  // Only where the plain launch has few workgroups: the x8 layer at B = 64 / f32 goes 38 -> 26 us (49
+  // tiles), the x4 layer with 196 tiles 20 -> 24 (profiles/r05k_scatter_split.txt).
+  k.ups_split = (UPS > 1 && k.vec4 && k.nbx * k.nby <= 128) ? UPS : 1;
+  const unsigned nwg = (unsigned)(k.nbx * k.nby * k.ups_split);
   // weights larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
   if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
   if constexpr (sizeof(typename T::elem) == 2 && BM == 64 && BN == 48 && UPS == 1 && KQ == 4) {
@@ -243,11 +262,9 @@ static int launch(ConvK k, hipStream_t s) {
   }
   if (k.flat) return SHAPY_EINVAL;
   if (UPS == 1 && k.pd3)
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, 1, KQ, 3>), dim3(k.nbx * k.nby),
-                       dim3(256), 0, s, k);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, 1, KQ, 3>), dim3(nwg), dim3(256), 0, s, k);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, UPS, KQ>), dim3(k.nbx * k.nby),
-                       dim3(256), 0, s, k);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, UPS, KQ>), dim3(nwg), dim3(256), 0, s, k);
   return (int)hipGetLastError();
 }
 
@@ -359,6 +376,7 @@ int conv_prepare(const ShapyConv &d, ConvK &k, int *empty) {
   k.no_allk = (d.tile & 0x20000) ? 1 : 0;
   // F(4x4) split-K (conv_wino4.hip): SHAPY_TILE_W4_KSPLIT(S) in the tile word, slab + counters from
   // the caller
+  k.ups_split = 1;
   k.ksplit = ((d.tile >> 21) & 3) + 1;
   k.split_ws = d.split_ws; k.split_bytes = 0; k.split_cnt = d.split_cnt;
   k.flat = flat ? 1 : 0;

@@ -25,6 +25,8 @@ def main():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--algo', default=None)
     ap.add_argument('--verbose', action='store_true')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='storage type of the traced run')
+    ap.add_argument('--batch', type=int, default=64, help='batch of the traced run (selects the split-K bucket)')
     ap.add_argument('--no-dag', action='store_true', help='the traced run used SHAPY_DAG=0 or --single-stream')
     ap.add_argument('--group', type=int, default=None, help='group_branches of the traced run (default: the product default)')
     args = ap.parse_args()
@@ -36,7 +38,8 @@ def main():
     if args.group is not None:
         net.backbone.group_branches = bool(args.group)
     net.backbone._dag_eff = net.backbone.dag and not args.no_dag        # the traced run: eager, multi-stream
-    plan = net.backbone._build_plan(args.size, args.size)
+    net.backbone._ksplit_eff = net.backbone.ksplit_policy(args.batch) if args.dtype == 'f32' else {}
+    plan = net.backbone._build_plan(args.size, args.size, bf16=args.dtype == 'bf16')
     # one kernel per op, except launch groups (one persistent kernel for `group` ops): the group's
     # first op stands for the launch
     ops, skip = [], 0
