@@ -100,15 +100,19 @@ typedef struct ShapyConv {
                          loop chunk by chunk, 0x40000 / 0x80000 three / one chunk(s) of loads in
                          flight.  Speed only: every setting computes the same convolution.
                          Two fields describe DATA / arithmetic instead: SHAPY_TILE_WINO4 (0x100000)
-                         says that wgt_wino holds F(4x4,3x3) filters (below); SHAPY_TILE_W4_KSPLIT(S)
-                         (bits 21..22 = S - 1, S = 1..4) runs such a layer with its K loop cut into S
+                         says that wgt_wino holds F(4x4,3x3) filters (below); SHAPY_TILE_KSPLIT(S)
+                         (bits 21..22 = S - 1, S = 1..4) runs the layer with its K loop cut into S
                          slices on S workgroups per output tile (split_ws / split_cnt below; the S
                          partial sums are added in slice order, so the result is deterministic but
-                         differs from S = 1 in the last bits).                                   */
+                         differs from S = 1 in the last bits).  Available on the F(4x4) kernel (Cin / 16
+                         divisible by S) and on the implicit-GEMM kernel (ups == 1, Cin % 32 == 0 in bf16,
+                         tiles up to 64 x 64; every slice must get at least one K chunk); anything
+                         else is SHAPY_EINVAL.                                                   */
   int32_t dtype;      /* storage type of in / wgt / res / out: SHAPY_DTYPE_F32 (f32 MFMA, exact
                          f32) or SHAPY_DTYPE_BF16 (bf16 MFMA, f32 accumulate; Cin % 8 == 0, and
                          Cin >= 32 with ups == 1 when Cin % 32 != 0: the flat-K kernel)          */
-  int32_t reserved0;
+  int32_t split_kib;  /* SHAPY_TILE_KSPLIT(S > 1): capacity of split_ws in KiB (the launch is refused, SHAPY_EINVAL,
+                         when it would need more); 0 otherwise                                  */
   const void *wgt_wino; /* NULL, or the Winograd F(2x2,3x3) transform of wgt for a float32
                          3x3 / stride 1 / pad 1 layer: U[p = 4i+j][Cin/16][Cout][16] float32,
                          U[i][j] = (G g G^T)[i][j] (shapy_amd/utils/winograd.py).  When given
@@ -121,15 +125,21 @@ typedef struct ShapyConv {
                          csrc/conv_wino4.hip (4x fewer MFMAs than the direct sum).  Tensors
                          beyond 1 GiB (the kernel's 32-bit offset scheme) run the direct kernel
                          on `wgt` instead; SHAPY_EINVAL when the layer shape does not qualify.  */
-  void *split_ws;     /* SHAPY_TILE_W4_KSPLIT(S > 1) only (ABI 8): S * B * ceil(Hi/4) * ceil(Wi/4) * 16
-                         * Cout floats of scratch, 16-byte aligned, private to this call while it runs */
-  int32_t *split_cnt; /* ... and 2 * ceil(B * ceil(Hi/4) * ceil(Wi/4) / 16) * (Cout / 16) int32
-                         arrival counters that are ZERO when the call starts; the kernel leaves them
-                         zero (so the same counters serve the next call on the same stream, but must
-                         be zeroed again after a failed / aborted launch)                         */
+  void *split_ws;     /* SHAPY_TILE_KSPLIT(S > 1) only (ABI 8): scratch for the partial sums, 16-byte
+                         aligned, private to this call while it runs.  F(4x4): S * B * ceil(Hi/4) *
+                         ceil(Wi/4) * 16 * Cout floats; implicit GEMM: S * Mpad * Npad floats with M = B * Ho
+                         * Wo and Cout rounded up to the tile the library picks (at most 64 x 64 for such
+                         layers: Mpad <= M + 63, Npad <= Cout + 63)                                */
+  int32_t *split_cnt; /* ... and int32 arrival counters that are ZERO when the call starts; the kernel
+                         leaves them zero (so the same counters serve the next call on the same stream,
+                         but must be zeroed again after a failed / aborted launch).  F(4x4): 2 * ceil(B *
+                         ceil(Hi/4) * ceil(Wi/4) / 16) * (Cout / 16); implicit GEMM: 8 per tile, at most
+                         8 * ceil(M / 32) * ceil(Cout / 48)                                         */
+  int32_t split_cnt_n; /* capacity of split_cnt in int32 (checked like split_kib)                   */
 } ShapyConv;
 #define SHAPY_TILE_WINO4 0x100000
-#define SHAPY_TILE_W4_KSPLIT(s) ((((s) - 1) & 3) << 21)
+#define SHAPY_TILE_KSPLIT(s) ((((s) - 1) & 3) << 21)
+#define SHAPY_TILE_W4_KSPLIT(s) SHAPY_TILE_KSPLIT(s)
 
 int shapy_conv2d(const ShapyConv *desc_host, void *stream);
 
@@ -173,13 +183,15 @@ typedef struct ShapyOp {
   int64_t wgt_off, bias_off;            /* float offsets into the weight blob; -1 = none     */
   int64_t wino_off;                     /* float offset of the Winograd-transformed filters
                                            (ShapyConv.wgt_wino) in the blob; -1 = none        */
-  int64_t split_off;                    /* split-K layers (SHAPY_TILE_W4_KSPLIT in `tile`, ABI 8):
+  int64_t split_off;                    /* split-K layers (SHAPY_TILE_KSPLIT in `tile`, ABI 8):
                                            per-image float offset of ShapyConv.split_ws in the
-                                           workspace (S * ceil(Hi/4) * ceil(Wi/4) * 16 * Cout
-                                           floats per image); -1 = none                        */
+                                           workspace; -1 = none                                */
   int64_t cnt_off;                      /* ... and per-image int32 offset of ShapyConv.split_cnt
-                                           in the `counters` argument (2 * ceil(ceil(Hi/4) *
-                                           ceil(Wi/4) / 16) * (Cout / 16) per image); -1 = none */
+                                           in the `counters` argument; -1 = none               */
+  int64_t split_floats, cnt_n;          /* per-image capacities of the two, the slab's in workspace
+                                           ELEMENTS (float32 or bf16) (the executor hands
+                                           B times these to the kernel launcher as split_kib /
+                                           split_cnt_n)                                         */
 } ShapyOp;
 
 /* input: [B,3,H,W] NCHW f32 (the reference's layout, iterative_regressor.py:623);

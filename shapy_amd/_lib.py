@@ -30,7 +30,7 @@ class ShapyConv(ctypes.Structure):
                 ('ksize', i32), ('stride', i32), ('pad', i32),
                 ('out_ld', i32), ('out_coff', i32), ('res_ld', i32), ('res_coff', i32),
                 ('relu', i32), ('ups', i32), ('tile', i32), ('dtype', i32),
-                ('reserved0', i32), ('wgt_wino', vp), ('split_ws', vp), ('split_cnt', vp)]
+                ('split_kib', i32), ('wgt_wino', vp), ('split_ws', vp), ('split_cnt', vp), ('split_cnt_n', i32)]
 
 
 class ShapyOp(ctypes.Structure):
@@ -42,7 +42,7 @@ class ShapyOp(ctypes.Structure):
                 ('sig', i32), ('wait', i32 * 3),
                 ('in_off', i64), ('out_off', i64), ('res_off', i64),
                 ('wgt_off', i64), ('bias_off', i64), ('wino_off', i64),
-                ('split_off', i64), ('cnt_off', i64)]
+                ('split_off', i64), ('cnt_off', i64), ('split_floats', i64), ('cnt_n', i64)]
 
 
 class ShapySmplxModel(ctypes.Structure):
@@ -75,10 +75,17 @@ TILE_WINO4 = 0x100000                   # ShapyConv.wgt_wino holds F(4x4,3x3) fi
 
 
 def tile_w4_ksplit(s):
-    """SHAPY_TILE_W4_KSPLIT(s): an F(4x4) layer with its K loop cut into s = 1..4 slices (bits 21..22)."""
+    """SHAPY_TILE_KSPLIT(s): a layer with its K loop cut into s = 1..4 slices (bits 21..22)."""
     if not 1 <= int(s) <= 4:
         raise ValueError(f'F(4x4) split-K: 1..4 slices, got {s}')
     return (int(s) - 1) << 21
+
+
+def igemm_split_sizes(Ho, Wo, cout, s):
+    """(slab floats per image, counter ints per image) that cover an implicit-GEMM split-K layer with Ho x Wo
+    output pixels per image whatever tile (<= 64 x 64) the library picks (include/shapy_hip.h)."""
+    hw = Ho * Wo
+    return s * (hw + 63) * (cout + 63), 8 * (hw // 32 + 1) * (cout // 48 + 1)
 
 
 def w4_split_sizes(H, W, cout, s):

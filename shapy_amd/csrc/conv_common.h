@@ -47,10 +47,12 @@ struct ConvK {
   int flat;                     // bf16, Cin % 32 != 0: flat-K kernel
   int pd3;                      // implicit GEMM: three chunks of global loads in flight
   int ups_split;                // upsample-scatter layers: workgroups per tile, each scatters ups / ups_split rows
-  int ksplit;                   // F(4x4): K slices per output tile (SHAPY_TILE_W4_KSPLIT), 1 = none
-  void *split_ws;               // ... their slab (ShapyConv.split_ws) and its size (conv2d_wino4)
+  int ksplit;                   // K slices per output tile (SHAPY_TILE_KSPLIT), 1 = none: F(4x4) and implicit GEMM
+  void *split_ws;               // ... their slab (ShapyConv.split_ws), the bytes the launch uses of it ...
   unsigned split_bytes;
-  int *split_cnt;               // ... and arrival counters (ShapyConv.split_cnt; zero between launches)
+  unsigned long long split_cap; // ... and what the caller provides (ShapyConv.split_kib)
+  int *split_cnt;               // ... arrival counters (ShapyConv.split_cnt; zero between launches) and how
+  int split_cnt_cap;            //     many the caller provides (ShapyConv.split_cnt_n)
 };
 
 // Winograd F(2x2,3x3) path of the float32 3x3 / stride-1 layers (conv_wino.hip)

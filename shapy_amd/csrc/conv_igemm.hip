@@ -33,8 +33,16 @@ namespace shapy {
 // FLAT: K = ks*ks*Cin is consumed as ONE flat index (chunks may straddle filter taps; every 16-byte
 // slot still lies inside one tap because Cin is a multiple of the slot width).  Lets bf16 run the
 // 48-channel branch without padding its tensors to 64 channels (Cin % 32 != 0).
-template <typename T, int BM, int BN, int WM, int WN, int UPS, int KQ, int PD = 1, bool FLAT = false>
+// SPLIT: split-K.  The K loop of a tile is cut into p.ksplit slices on as many workgroups (neighbours in
+// dispatch order); every WAVE is a reduction unit of its own (its TM x TN accumulator tiles): slices exchange
+// partial accumulators through a slab (write-through stores, one contiguous 1 KB run per tile and wave) and the
+// last wave unit to arrive adds them IN SLICE ORDER and runs the epilogue -- the protocol of the F(4x4) kernel
+// (conv_wino4.h: Wino4Split), for the K-deep layers on small maps that stay on this kernel: every 3x3 conv in
+// bf16 storage, the head's 1x1 GEMMs and the stride-2 fuse convs at small batches.
+template <typename T, int BM, int BN, int WM, int WN, int UPS, int KQ, int PD = 1, bool FLAT = false,
+          bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
+  static_assert(!SPLIT || (UPS == 1 && !FLAT), "split-K: plain epilogue, per-tap K chunks");
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(KQ == 4 || KQ == 8, "16-byte slots per staged row");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -62,6 +70,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     wg /= G;
     dy0 = part * (UPS / G);
     dy1 = dy0 + UPS / G;
+  }
+  int slice = 0;
+  if constexpr (SPLIT) {
+    slice = wg % p.ksplit;
+    wg /= p.ksplit;
   }
   const int m_blk = (wg / p.nbx) * BM, n_blk = (wg % p.nbx) * BN;
   const int kq = t % KQ, lrow = t / KQ;
@@ -102,22 +115,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   // chunk iterator state for the NEXT chunk to be fetched (FLAT: per thread -- the slots of one
   // chunk may belong to different taps; c0 / kflat = channel / flat k of this thread's slot)
   int kh = 0, kw = 0, c0 = FLAT ? kq * T::EPS : 0, kflat = kq * T::EPS;
-  const int n_chunks = FLAT ? (Kw + BK - 1) / BK : p.ks * p.ks * (p.Cin / BK);
+  int n_chunks = FLAT ? (Kw + BK - 1) / BK : p.ks * p.ks * (p.Cin / BK);
+  if constexpr (SPLIT) {
+    // this slice's chunks [c_begin, c_begin + n_chunks) of the layer's (the launcher guarantees >= 1 each)
+    const int cps = (n_chunks + p.ksplit - 1) / p.ksplit, c_begin = slice * cps;
+    n_chunks = n_chunks - c_begin < cps ? n_chunks - c_begin : cps;
+    const int cpt = p.Cin / BK, tap = c_begin / cpt;
+    c0 = (c_begin % cpt) * BK;
+    kh = tap / p.ks;
+    kw = tap % p.ks;
+  }
+  int left = n_chunks;                         // chunks still to be fetched: later requests read zeros
 
   auto gload = [&](int set) {
     const int tap_in = ((kh * p.Wi + kw) * p.in_ld + c0) * ESZ;
     const int tap_w = FLAT ? kflat * ESZ : ((kh * p.ks + kw) * p.Cin + c0) * ESZ;
+    const bool live = left > 0;
+    --left;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const bool ok = (unsigned)(a_h[i] + kh) < (unsigned)p.Hi &&
                       (unsigned)(a_w[i] + kw) < (unsigned)p.Wi;
       a_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(
-          rs_in, (ok && kh < p.ks) ? a_off[i] + tap_in : OOB, 0, 0);
+          rs_in, (ok && live) ? a_off[i] + tap_in : OOB, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i)
       b_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(
-          rs_w, (b_off[i] == OOB || kh >= p.ks) ? OOB : b_off[i] + tap_w, 0, 0);
+          rs_w, (b_off[i] == OOB || !live) ? OOB : b_off[i] + tap_w, 0, 0);
     c0 += BK;
     kflat += BK;
     if (FLAT ? c0 >= p.Cin : c0 == p.Cin) {          // FLAT: BK <= Cin, at most one tap per step
@@ -226,6 +251,70 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     }
   }
 
+  if constexpr (SPLIT) {
+    const int S = p.ksplit;
+    const int unit = wg * 4 + wave, n_units = p.nbx * p.nby * 4;
+    int *cnt = p.split_cnt + 2 * unit;
+    int tk = 0;
+    if (lane == 0) tk = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ticket = __builtin_amdgcn_readfirstlane(tk);
+    const __amdgpu_buffer_rsrc_t rs_slab =
+        __builtin_amdgcn_make_buffer_rsrc(p.split_ws, 0, p.split_bytes, 0x00020000);
+    auto slab_off = [&](int sl, int tile) {
+      return ((sl * n_units + unit) * (TM * TN) + tile) * 1024 + lane * 16;
+    };
+    if (ticket != S - 1) {
+      // publish this slice's partial accumulators (write-through), drain, report, leave
+      int off[TM * TN];
+#pragma unroll
+      for (int q = 0; q < TM * TN; ++q) off[q] = slab_off(slice, q);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs_slab,
+                                                 off[i * TN + j], 0, /*sc1*/ 16);
+      asm volatile("s_nop 1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) (void)__hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    // last to arrive: every other slice holds a ticket, i.e. is resident and past its K loop
+    if (lane == 0)
+      while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S - 1)
+        __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    f32x4 sum[TM][TN];
+    for (int sl = 0; sl < S; ++sl) {
+      f32x4 term[TM][TN];
+      if (sl == slice) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) term[i][j] = acc[i][j];
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            term[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       rs_slab, slab_off(sl, i * TN + j), 0, /*sc1*/ 16));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) sum[i][j] = sl == 0 ? term[i][j] : sum[i][j] + term[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = sum[i][j];
+    if (lane == 0) {
+      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
   if constexpr (VEC) {
     if (p.vec4) {
       conv_epilogue_vec<T, TM, TN, UPS>(p, acc, lds + wave * (LDS_EPI / 4), m_blk + wm * (BM / WM),
@@ -261,6 +350,25 @@ static int launch(ConvK k, hipStream_t s) {
     }
   }
   if (k.flat) return SHAPY_EINVAL;
+  if (k.ksplit > 1) {
+    // split-K (the plan's choice, SHAPY_TILE_KSPLIT): plain layers on the small tiles only
+    if constexpr (UPS == 1 && BM <= 64 && BN <= 64) {
+      const int S = k.ksplit, n_all = k.ks * k.ks * (k.Cin / (KQ * T::EPS)), cps = (n_all + S - 1) / S;
+      const unsigned long long slab = 4ull * S * k.nbx * k.nby * BM * BN;
+      if ((S - 1) * cps >= n_all || !k.split_ws || !k.split_cnt || ((uintptr_t)k.split_ws & 15) ||
+          slab > 0x40000000ull || slab > k.split_cap || 8 * k.nbx * k.nby > k.split_cnt_cap)
+        return SHAPY_EINVAL;
+      k.split_bytes = (unsigned)slab;
+      const dim3 grid((unsigned)(k.nbx * k.nby * S));
+      if (k.pd3)
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, 1, KQ, 3, false, true>), grid, dim3(256), 0, s, k);
+      else
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, 1, KQ, 1, false, true>), grid, dim3(256), 0, s, k);
+      return (int)hipGetLastError();
+    } else {
+      return SHAPY_EINVAL;
+    }
+  }
   if (UPS == 1 && k.pd3)
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, 1, KQ, 3>), dim3(nwg), dim3(256), 0, s, k);
   else
@@ -379,6 +487,8 @@ int conv_prepare(const ShapyConv &d, ConvK &k, int *empty) {
   k.ups_split = 1;
   k.ksplit = ((d.tile >> 21) & 3) + 1;
   k.split_ws = d.split_ws; k.split_bytes = 0; k.split_cnt = d.split_cnt;
+  k.split_cap = (unsigned long long)(d.split_kib > 0 ? d.split_kib : 0) << 10;
+  k.split_cnt_cap = d.split_cnt_n > 0 ? d.split_cnt_n : 0;
   k.flat = flat ? 1 : 0;
   return SHAPY_OK;
 }

@@ -306,7 +306,7 @@ int conv2d_wino4(ConvK k, hipStream_t s) {
     // slab: S x (Cout / 16 wave units) x 16 pixels x tiles x 64 bytes; counters: 2 per (m tile, unit)
     const unsigned long long slab = 64ull * 16 * k.wino_tiles * (k.Cout / 16) * S;
     if (S > 4 || chunks % S || !k.split_ws || !k.split_cnt || ((uintptr_t)k.split_ws & 15) ||
-        slab > 0x40000000ull)
+        slab > 0x40000000ull || slab > k.split_cap || 2 * k.nby * (k.Cout / 16) > k.split_cnt_cap)
       return SHAPY_EINVAL;
     k.split_bytes = (unsigned)slab;
   }

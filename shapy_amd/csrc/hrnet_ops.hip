@@ -305,12 +305,22 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
       d.Ho = q.Ho; d.Wo = q.Wo; d.Cout = q.Cout; d.ksize = q.ksize; d.stride = q.stride;
       d.pad = q.pad; d.out_ld = q.out_ld; d.out_coff = q.out_coff; d.res_ld = q.res_ld;
       d.res_coff = q.res_coff; d.relu = q.relu; d.ups = q.ups; d.tile = q.tile;
-      d.reserved0 = 0;
+      d.split_kib = 0;
+      d.split_cnt_n = 0;
       d.wgt_wino = (dtype == SHAPY_DTYPE_F32 && q.wino_off >= 0) ? wf32 + q.wino_off : nullptr;
       // split-K layers: slab in the workspace, arrival counters in the caller's counter array
       d.split_ws = buf(q.split_off);
-      d.split_cnt = (counters && q.cnt_off >= 0 && q.cnt_off < cnt_per_img) ? counters + q.cnt_off * (int64_t)B
-                                                                            : nullptr;
+      if (d.split_ws && q.split_floats > 0 && q.split_off + q.split_floats <= ws_per_img) {
+        const int64_t kib = q.split_floats * (int64_t)B * esz / 1024;     // (elements of the workspace's type)
+        d.split_kib = kib > 0x7fffffff ? 0x7fffffff : (int32_t)kib;
+      }
+      if (counters && q.cnt_off >= 0 && q.cnt_n > 0 && q.cnt_off + q.cnt_n <= cnt_per_img) {
+        d.split_cnt = counters + q.cnt_off * (int64_t)B;
+        const int64_t n = q.cnt_n * (int64_t)B;
+        d.split_cnt_n = n > 0x7fffffff ? 0x7fffffff : (int32_t)n;
+      } else {
+        d.split_cnt = nullptr;
+      }
     };
     if (o.type == SHAPY_OP_CONV) {
       int rc = SHAPY_OK;

@@ -46,6 +46,16 @@ DEFAULT_WINO4_KSPLIT_BY_BATCH = (
     (None, {(384, 4): 2}),
 )
 DEFAULT_WINO4_KSPLIT = DEFAULT_WINO4_KSPLIT_BY_BATCH[-1][1]        # the headline batch's policy
+#: split-K of implicit-GEMM layers by batch bucket: {(Cin, ksize, most output pixels per image): K slices}.
+#: float32 (profiles/r05l_direct_ksplit_sweep.txt): the head's 1x1 GEMMs (K = 2,048: 64 chunks) and the stride-2
+#: fuse convs on the small maps shorten the B <= 8 chain: backbone B = 1 3.56 -> 3.24 ms, B = 8 4.06 -> 3.86;
+#: nothing from B = 32 on.  bf16 storage: no policy helps at bs 32 / 64 (its launches are not bound by their K
+#: loops: 384 @7x7 23 -> 19 us isolated, nil end to end; 192 @14x14 16 -> 23 us) -- none.
+DEFAULT_DIRECT_KSPLIT_BY_BATCH = (
+    (8, {(2048, 1, 49): 4, (1536, 1, 49): 4, (512, 1, 49): 2, (192, 3, 49): 4, (96, 3, 196): 2, (96, 3, 49): 2}),
+    (None, {}),
+)
+DEFAULT_DIRECT_KSPLIT_BY_BATCH_BF16 = ((None, {}),)
 
 
 # ------------------------------------------------------------------------------------------
@@ -270,6 +280,12 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 cin, tmax = key.split('@')
                 self.wino4_ksplit[(int(cin), int(tmax))] = int(sl)
         self._ksplit_eff = None          # the policy of the plan being built (None: the largest bucket's)
+        #: split-K of the implicit-GEMM layers, same idea: {(Cin, ksize, most output pixels per image): S} per
+        #: batch bucket, float32 and bf16 storage apart (direct_ksplit = a dict pins one policy)
+        self.direct_ksplit_by_batch = tuple((b, dict(p)) for b, p in DEFAULT_DIRECT_KSPLIT_BY_BATCH)
+        self.direct_ksplit_by_batch_bf16 = tuple((b, dict(p)) for b, p in DEFAULT_DIRECT_KSPLIT_BY_BATCH_BF16)
+        self.direct_ksplit = None
+        self._direct_ksplit_eff = None
 
         #: conv_algo='winograd4': the convs at the same depth of a HighResolutionModule's parallel
         #: branches as ONE persistent grouped launch (csrc/conv_wino4g.hip) instead of one launch
@@ -446,6 +462,31 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 return pol
         return self.wino4_ksplit_by_batch[-1][1]
 
+    def direct_ksplit_policy(self, B=None, bf16=False):
+        """{(Cin, ksize, most output pixels per image): S} for the implicit-GEMM layers of a forward with batch B."""
+        if self.direct_ksplit is not None:
+            return self.direct_ksplit
+        table = self.direct_ksplit_by_batch_bf16 if bf16 else self.direct_ksplit_by_batch
+        for max_b, pol in table:
+            if max_b is None or (B is not None and B <= max_b):
+                return pol
+        return table[-1][1]
+
+    def _direct_ksplit(self, cin, ks, out_pixels, bf16):
+        pol = self._direct_ksplit_eff if self._direct_ksplit_eff is not None else self.direct_ksplit_policy(None, bf16)
+        eps = 8 if bf16 else 4
+        if cin % (4 * eps):                    # the flat-K bf16 kernel has no split form
+            return 1
+        best = 1
+        for (c, k, pmax), sl in pol.items():
+            if c == cin and k == ks and out_pixels <= pmax:
+                best = max(best, int(sl))
+        # every slice needs at least one K chunk, whichever chunk length the library picks (up to 8 slots)
+        n_min = ks * ks * (cin // (8 * eps)) if cin % (8 * eps) == 0 else ks * ks * (cin // (4 * eps))
+        while best > 1 and (best - 1) * -(-n_min // best) >= n_min:
+            best -= 1
+        return best
+
     def _ksplit(self, cin, Hi, Wi):
         """K slices of an F(4x4) layer under the policy of the plan being built; 1 = no split."""
         t = ((Hi + 3) // 4) * ((Wi + 3) // 4)
@@ -480,7 +521,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             if outb is None:
                 outb = P.buf(Ho * ups, Wo * ups, cout_p)
             wino_off, wino_flag = -1, 0
-            scrb, cnt_off = None, -1
+            scrb, cnt_off, cnt_n = None, -1, 0
             forced = self.layer_algo.get(name)       # Winograd guard (calibrate): per-layer demotion
             if forced == 'direct':
                 pass
@@ -492,13 +533,23 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 # split-K (never inside a persistent grouped launch, which has no such form)
                 sl = 1 if group_member else self._ksplit(cin_p, Hi, Wi)
                 if sl > 1:
-                    slab, ncnt = _lib.w4_split_sizes(Hi, Wi, cout_p, sl)
+                    slab, cnt_n = _lib.w4_split_sizes(Hi, Wi, cout_p, sl)
                     scrb = P.buf(1, 1, slab)
-                    cnt_off, P.cnt_ints = P.cnt_ints, P.cnt_ints + ncnt
+                    cnt_off, P.cnt_ints = P.cnt_ints, P.cnt_ints + cnt_n
                     wino_flag |= _lib.tile_w4_ksplit(sl)
             elif not (bf16 or x6) and self._use_wino(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
                 wino_off = P.add_weights(winograd.transform_filters(w))
+            if wino_off < 0 and not x6 and ups == 1 and not group_member:
+                # implicit-GEMM layers (every conv in bf16; strided / 1x1 / demoted layers in f32): split-K for
+                # the K-deep ones on small maps (csrc/conv_igemm.hip; never the flat-K bf16 kernel)
+                sl = self._direct_ksplit(cin_p, ks, Ho * Wo, bf16)
+                if sl > 1:
+                    slab, cnt_n = _lib.igemm_split_sizes(Ho, Wo, cout_p, sl)
+                    scrb = P.buf(1, 1, slab * (2 if bf16 else 1))    # float32 partials in a bf16-element arena
+                    cnt_off, P.cnt_ints = P.cnt_ints, P.cnt_ints + cnt_n
+                    wino_flag |= _lib.tile_w4_ksplit(sl)
             P.op(type=_lib.OP_CONV, lane=lane, inb=inb, outb=outb, resb=res, scrb=scrb, cnt_off=cnt_off,
+                 cnt_n=cnt_n,
                  Hi=Hi, Wi=Wi, Cin=cin_p,
                  in_ld=inb.C, Ho=Ho, Wo=Wo, Cout=cout_p, ksize=ks, stride=st, pad=pad,
                  out_ld=out_ld or outb.C, out_coff=out_coff,
@@ -720,19 +771,20 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             self._engine = {}
             self._engine_ver = ver
         pol = self.ksplit_policy(B) if self.compute_dtype == 'f32' else {}
+        dpol = self.direct_ksplit_policy(B, bf16) if self.compute_dtype in ('f32', 'bf16') else {}
         key_w = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
                  self.wino4_min_hw, self._group_on(), self._dag_eff, tuple(self.wino4_n64),
                  tuple(sorted(self.layer_algo.items())), self.tile_flags,
                  tuple(sorted(self.tile_overrides.items())))
-        key = key_w + (tuple(sorted(pol.items())),)
+        key = key_w + (tuple(sorted(pol.items())) + tuple(sorted(dpol.items())),)
         eng = self._engine.get(key)
         if eng is not None:
             return eng
-        self._ksplit_eff = pol
+        self._ksplit_eff, self._direct_ksplit_eff = pol, dpol
         try:
             P = self._build_plan(H, W, bf16, self.compute_dtype == 'f32x6')
         finally:
-            self._ksplit_eff = None
+            self._ksplit_eff = self._direct_ksplit_eff = None
         P.sync_plan()
         ws_per_img = P.allocate()
         n = len(P.ops)
@@ -749,7 +801,9 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             a.out_off = -1 if o['outb'] is None else o['outb'].off
             a.res_off = -1 if o['resb'] is None else o['resb'].off
             a.split_off = -1 if o.get('scrb') is None else o['scrb'].off
+            a.split_floats = 0 if o.get('scrb') is None else o['scrb'].size
             a.cnt_off = int(o.get('cnt_off', -1))
+            a.cnt_n = int(o.get('cnt_n', 0))
         # the weight blob does not depend on the split policy (same layers, same order, same transforms):
         # plans that differ in nothing else share ONE device copy (1.3 GB with the default algorithm)
         weights = next((e['weights'] for k, e in self._engine.items()
@@ -878,7 +932,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             if o['type'] == _lib.OP_CONV and o.get('wino_off', -1) >= 0:
                 algo = 'winograd4' if o['tile'] & _lib.TILE_WINO4 else 'winograd'
                 keep = op.tile, op.wino_off, op.out_off, op.out_ld, op.out_coff
-                op.tile = (op.tile & ~_lib.TILE_WINO4) | 0x2000         # never Winograd: direct kernel
+                # never Winograd: direct kernel, unsplit (the layer's slab is sized for its Winograd form)
+                op.tile = (op.tile & ~(_lib.TILE_WINO4 | (3 << 21))) | 0x2000
                 op.wino_off, op.out_off, op.out_ld, op.out_coff = -1, scratch_off, o['Cout'], 0
                 run(one)
                 op.tile, op.wino_off, op.out_off, op.out_ld, op.out_coff = keep

@@ -68,12 +68,18 @@ def _conv_call(lib, x, w, b, res=None, relu=False, stride=1, pad=0, ups=1, tile=
             if split_bufs is None:
                 split_bufs = (torch.full((slab * B,), float('nan'), device=x.device),
                               torch.zeros(ncnt * B, dtype=torch.int32, device=x.device))
-            d.split_ws, d.split_cnt = split_bufs[0].data_ptr(), split_bufs[1].data_ptr()
-            d.tile |= _lib.tile_w4_ksplit(ksplit)
     elif wino:                                         # Winograd-transformed filters as well
         from shapy_amd.utils import winograd
         wu = torch.from_numpy(winograd.transform_filters(w.cpu().numpy())).to(x.device)
         d.wgt_wino = wu.data_ptr()
+    if ksplit > 1:
+        if split_bufs is None:                         # implicit-GEMM split-K (no F(4x4) filters given)
+            slab, ncnt = _lib.igemm_split_sizes(Ho, Wo, O, ksplit)
+            split_bufs = (torch.full((slab * B,), float('nan'), device=x.device),
+                          torch.zeros(ncnt * B, dtype=torch.int32, device=x.device))
+        d.split_ws, d.split_cnt = split_bufs[0].data_ptr(), split_bufs[1].data_ptr()
+        d.split_kib, d.split_cnt_n = split_bufs[0].numel() * 4 // 1024, split_bufs[1].numel()
+        d.tile |= _lib.tile_w4_ksplit(ksplit)
     rc = lib.shapy_conv2d(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
     torch.cuda.synchronize()
@@ -271,6 +277,53 @@ def test_conv_winograd4_split_k_vs_float64(lib, case):
     assert all(torch.equal(o, outs[0]) for o in outs[1:]), 'split-K result changes from launch to launch'
 
 
+# implicit-GEMM split-K (csrc/conv_igemm.hip, SPLIT): B, H, W, Cin, Cout, ks, stride, res, relu, S, bf16
+IGEMM_SPLIT_CASES = [
+    (32, 7, 7, 384, 384, 3, 1, True, True, 4, True),        # the 7x7 branch in bf16 storage (configs[2] shard)
+    (32, 14, 14, 192, 192, 3, 1, True, True, 2, True),      # the 14x14 branch, bf16
+    (8, 7, 7, 2048, 512, 1, 1, False, True, 2, False),      # head 1x1, float32, small batch
+    (3, 14, 14, 192, 384, 3, 2, True, False, 3, False),     # stride-2 fuse conv, three slices of 54 chunks
+    (1, 7, 7, 512, 2048, 1, 1, True, True, 4, False),       # M tail (49 rows), N = 2048
+    (5, 9, 9, 64, 64, 3, 1, False, True, 2, True),          # bf16, short K (18 chunks of 32), 64-wide tile
+]
+
+
+@pytest.mark.parametrize('case', IGEMM_SPLIT_CASES, ids=[str(c) for c in IGEMM_SPLIT_CASES])
+def test_conv_igemm_split_k_vs_unsplit_and_float64(lib, case):
+    """Split-K on the implicit-GEMM kernel: against float64 and against the unsplit launch (same products, S
+    partial sums added in slice order), repeated on the same slab / counters (left zero by the kernel;
+    bit-identical from launch to launch), float32 and bf16 storage."""
+    B, H, W, Cin, Cout, ks, st, use_res, relu, S, bf16 = case
+    dt = torch.bfloat16 if bf16 else torch.float32
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, H, W, Cin, generator=g).cuda().to(dt)
+    w = (torch.randn(Cout, ks, ks, Cin, generator=g) / np.sqrt(ks * ks * Cin)).cuda().to(dt)
+    b = torch.randn(Cout, generator=g).cuda()
+    pad = ks // 2
+    Ho, Wo = (H + 2 * pad - ks) // st + 1, (W + 2 * pad - ks) // st + 1
+    res = torch.randn(B, Ho, Wo, Cout, generator=g).cuda().to(dt) if use_res else None
+    from shapy_amd import _lib
+    slab, ncnt = _lib.igemm_split_sizes(Ho, Wo, Cout, S)
+    bufs = (torch.full((slab * B,), float('nan'), device='cuda'),
+            torch.zeros(ncnt * B, dtype=torch.int32, device='cuda'))
+    base = _conv_call(lib, x, w, b, res, relu, st, pad, tile=0x2000)
+    ref = _conv_ref(x.float(), w.float(), b, res.float() if use_res else None, relu, st, pad)
+    tol = (3e-2 if bf16 else 2e-5)
+    assert (base.float().cpu().double() - ref).abs().max().item() < tol
+    outs = []
+    for rep in range(5):
+        if rep % 2:
+            junk = torch.randn(4096, 4096, device='cuda')
+            junk = junk @ junk
+        outs.append(_conv_call(lib, x, w, b, res, relu, st, pad, tile=0x2000, ksplit=S, split_bufs=bufs).clone())
+        assert int(bufs[1].abs().sum().item()) == 0, 'arrival counters not back to zero'
+    e = (outs[0].float().cpu().double() - ref).abs().max().item()
+    d = (outs[0].float() - base.float()).abs().max().item()
+    print(f'igemm split-K S={S} bf16={bf16}: err vs float64 {e:.3e}, vs unsplit {d:.3e}')
+    assert e < tol and d < tol
+    assert all(torch.equal(o, outs[0]) for o in outs[1:]), 'split-K result changes from launch to launch'
+
+
 def test_conv_winograd4_split_k_refusals(lib):
     """No slab / counters, a slice count that does not divide the chunks, S on a non-F(4x4) layer."""
     from shapy_amd import _lib
@@ -291,8 +344,12 @@ def test_conv_winograd4_split_k_refusals(lib):
         d.tile = _lib.TILE_WINO4 | _lib.tile_w4_ksplit(S)
         if with_bufs:
             d.split_ws, d.split_cnt = ws.data_ptr(), cnt.data_ptr()
+            d.split_kib, d.split_cnt_n = ws.numel() * 4 // 1024, cnt.numel()
+            if with_bufs == 'small':
+                d.split_kib = 1                          # a slab that is too small: refused, not overrun
         return lib.shapy_conv2d(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert call(2, False) == -1          # SHAPY_EINVAL: no slab
+    assert call(2, 'small') == -1        # ... or one below the launch's need
     assert call(4, True) == -1           # 6 chunks do not split four ways
     torch.cuda.synchronize()
     assert torch.equal(out, torch.full_like(out, 7.0))      # nothing was launched

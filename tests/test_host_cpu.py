@@ -154,17 +154,23 @@ def test_plan_orders_every_memory_hazard(hrnet, dag, group, ksplit):
     try:
         hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw = dag, group, 'winograd4', 7
         hrnet.wino4_ksplit = ksplit
+        small = (96, 49) in ksplit               # the B <= 8 bucket: its implicit-GEMM split layers as well
+        if small:
+            from shapy_amd.models.backbone.hrnet import DEFAULT_DIRECT_KSPLIT_BY_BATCH
+            hrnet.direct_ksplit = dict(DEFAULT_DIRECT_KSPLIT_BY_BATCH[0][1])
         P = hrnet._build_plan(224, 224)
         waits = P.sync_plan()
         total = P.allocate()
     finally:
+        hrnet.direct_ksplit = None
         hrnet._dag_eff, hrnet.group_branches, hrnet.conv_algo, hrnet.wino4_min_hw, hrnet.wino4_ksplit = keep
-    n_split = sum(1 for o in P.ops if o.get('scrb') is not None)
+    n_direct = sum(1 for o in P.ops if o.get('scrb') is not None and not o['tile'] & _lib.TILE_WINO4)
+    assert (n_direct > 20) == small              # head 1x1 GEMMs + stride-2 fuse / transition / subsample convs
+    n_split = sum(1 for o in P.ops if o.get('scrb') is not None) - n_direct
     # 384 -> 384 @7x7: 3 modules x 8 convs, 192 -> 192 @14x14: 7 modules x 8; none inside launch groups
     assert n_split == (0 if not ksplit else 0 if group else
                        24 + (56 if (192, 16) in ksplit else 0) + (64 if (96, 49) in ksplit else 0))
-    cnts = sorted((o['cnt_off'], _lib.w4_split_sizes(o['Hi'], o['Wi'], o['Cout'], 2)[1])   # (independent of S)
-                  for o in P.ops if o.get('scrb') is not None)
+    cnts = sorted((o['cnt_off'], o['cnt_n']) for o in P.ops if o.get('scrb') is not None)
     assert all(c0 + n <= c1 for (c0, n), (c1, _) in zip(cnts, cnts[1:]))      # disjoint counter slices
     assert not cnts or cnts[-1][0] + cnts[-1][1] == P.cnt_ints
     ops = P.ops

@@ -69,7 +69,9 @@ def main():
         wu = wu4 = None
         for tile in args.tiles.split(','):
             d = _lib.ShapyConv()
-            if tile == 'wino4' or tile.startswith('wino4k'):   # Winograd F(4x4,3x3) (conv_wino4.hip); wino4kS: split-K, S slices
+            if tile.startswith('autok'):               # implicit GEMM, automatic tile, split-K with S slices
+                pass
+            elif tile == 'wino4' or tile.startswith('wino4k'):   # Winograd F(4x4,3x3) (conv_wino4.hip); wino4kS: split-K, S slices
                 from shapy_amd.utils import winograd
                 if args.dtype != 'f32' or not winograd.eligible4(ks, st, pad, Cin, Cout, ups) \
                         or min(Hi, Wi) < args.wino4_min_hw:
@@ -92,7 +94,17 @@ def main():
             d.ksize, d.stride, d.pad = ks, st, pad
             d.out_ld = Cout; d.out_coff = 0; d.res_ld = Cout if has_res else 0; d.res_coff = 0
             d.relu = int(relu); d.ups = ups
-            if tile.startswith('wino4k'):
+            if tile.startswith('autok'):
+                S = int(tile[5:])
+                if ups != 1 or (bf16 and Cin % 32):
+                    continue
+                slab, ncnt = _lib.igemm_split_sizes(Ho, Wo, Cout, S)
+                split_ws = torch.empty(slab * B, device='cuda')
+                split_cnt = torch.zeros(ncnt * B, dtype=torch.int32, device='cuda')
+                d.split_ws, d.split_cnt = split_ws.data_ptr(), split_cnt.data_ptr()
+                d.split_kib, d.split_cnt_n = split_ws.numel() * 4 // 1024, split_cnt.numel()
+                d.tile = 0x2000 | _lib.tile_w4_ksplit(S)
+            elif tile.startswith('wino4k'):
                 S = int(tile[6:])
                 if (Cin // 16) % S:
                     continue
@@ -100,6 +112,7 @@ def main():
                 split_ws = torch.empty(slab * B, device='cuda')
                 split_cnt = torch.zeros(ncnt * B, dtype=torch.int32, device='cuda')
                 d.split_ws, d.split_cnt = split_ws.data_ptr(), split_cnt.data_ptr()
+                d.split_kib, d.split_cnt_n = split_ws.numel() * 4 // 1024, split_cnt.numel()
                 d.tile = _lib.TILE_WINO4 | _lib.tile_w4_ksplit(S)
             else:
                 d.tile = {'wino': 0, 'wino1': 0x4000, 'wino2': 0x8000, 'winochunk': 0x20000,
