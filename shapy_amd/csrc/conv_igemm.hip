@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   auto gload = [&](int set) {
     const int tap_in = ((kh * p.Wi + kw) * p.in_ld + c0) * ESZ;
     const int tap_w = FLAT ? kflat * ESZ : ((kh * p.ks + kw) * p.Cin + c0) * ESZ;
-    const bool live = left > 0;
+    // (kh < ks: the flat-K kernel's LAST chunk may reach past the K extent in some of its slots)
+    const bool live = left > 0 && kh < p.ks;
     --left;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
