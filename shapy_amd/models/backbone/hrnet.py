@@ -419,6 +419,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         automatically when a parameter / buffer version changes (``_compile``), after
         ``load_state_dict`` and after ``.to()`` / ``.cuda()``."""
         self._engine = {}
+        self.__dict__.pop('_xform_cache', None)
         self._calibrated_ver = None
         self._drop_guard_demotions()
         self._drop_version_cache()
@@ -426,12 +427,14 @@ class HighResolutionNet(VersionedWeights, nn.Module):
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._engine = {}
+        self.__dict__.pop('_xform_cache', None)
         self._drop_version_cache()
         return out
 
     def __getstate__(self):
         st = self.__dict__.copy()
         st['_engine'] = {}
+        st.pop('_xform_cache', None)
         st['_ver_tensors'] = None
         return st
 
@@ -487,6 +490,22 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             best -= 1
         return best
 
+    def _xform(self, name, kind, w):
+        """Winograd-transformed filters of a layer (float64 transform on the host), memoised across the plans of
+        one weight version: the batch buckets compile the same 209 transforms otherwise (seconds each time)."""
+        cache = self.__dict__.setdefault('_xform_cache', {})
+        ver = self._engine_ver
+        if cache.get('ver') != ver:
+            cache.clear()
+            cache['ver'] = ver
+        key = (name, kind, w.shape)
+        if key not in cache or not name:
+            u = winograd.transform_filters4(w) if kind == 4 else winograd.transform_filters(w)
+            if not name:
+                return u
+            cache[key] = u
+        return cache[key]
+
     def _ksplit(self, cin, Hi, Wi):
         """K slices of an F(4x4) layer under the policy of the plan being built; 1 = no split."""
         t = ((Hi + 3) // 4) * ((Wi + 3) // 4)
@@ -526,9 +545,9 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             if forced == 'direct':
                 pass
             elif forced == 'winograd' and not (bf16 or x6) and winograd.eligible(ks, st, pad, cin_p, cout_p, ups):
-                wino_off = P.add_weights(winograd.transform_filters(w))
+                wino_off = P.add_weights(self._xform(name, 2, w))
             elif not (bf16 or x6) and self._use_wino4(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
-                wino_off = P.add_weights(winograd.transform_filters4(w))
+                wino_off = P.add_weights(self._xform(name, 4, w))
                 wino_flag = _lib.TILE_WINO4
                 # split-K (never inside a persistent grouped launch, which has no such form)
                 sl = 1 if group_member else self._ksplit(cin_p, Hi, Wi)
@@ -538,7 +557,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                     cnt_off, P.cnt_ints = P.cnt_ints, P.cnt_ints + cnt_n
                     wino_flag |= _lib.tile_w4_ksplit(sl)
             elif not (bf16 or x6) and self._use_wino(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
-                wino_off = P.add_weights(winograd.transform_filters(w))
+                wino_off = P.add_weights(self._xform(name, 2, w))
             if wino_off < 0 and not x6 and ups == 1 and not group_member:
                 # implicit-GEMM layers (every conv in bf16; strided / 1x1 / demoted layers in f32): split-K for
                 # the K-deep ones on small maps (csrc/conv_igemm.hip; never the flat-K bf16 kernel)
