@@ -570,32 +570,38 @@ def also_records(args, net, x):
     # configs[2]'s per-GPU shard (bf16 storage, bs 32) and the 256 x 256 crop on the SAME network
     bb = net.backbone
     keep = bb.compute_dtype
-    for tag, dtype, B, size in (('configs2_bf16_b32_per_gpu_shard', 'bf16', 32, args.size),
-                                ('f32_256x256_reference_default_crop', 'f32', args.batch, 256)):
+    pipe_on = getattr(args, 'pipeline', 'on') == 'on' and not getattr(args, 'single_stream', False)
+    for tag, dtype, B, size, pipe in (('configs2_bf16_b32_per_gpu_shard', 'bf16', 32, args.size, pipe_on),
+                                      ('f32_256x256_reference_default_crop', 'f32', args.batch, 256, pipe_on),
+                                      ('headline_one_forward_at_a_time', args.dtype, args.batch, args.size, False)):
+        if tag.startswith('headline') and not pipe_on:
+            continue
         try:
             from shapy_amd.utils import synthetic as syn
             xs = x[:B] if size == args.size else torch.from_numpy(
                 syn.synthetic_images(B, size, 100)).cuda()
+            nxt = {'next_images': xs} if pipe else {}
             with torch.no_grad():
                 bb.compute_dtype = 'f32'
                 ref = net(xs, None) if dtype != 'f32' else None
                 bb.compute_dtype = dtype
                 for _ in range(3):
-                    o = net(xs, None)
+                    o = net(xs, None, **nxt)
                 ev0, ev1 = hip_events(10)
                 idx = {'i': 0}
-                h0 = bb.register_forward_pre_hook(lambda m, a: ev0[idx['i']].record())
+                h0 = bb.register_forward_pre_hook(lambda m, a, kw=None: ev0[idx['i']].record())
                 h1 = bb.register_forward_hook(lambda m, a, o_: ev1[idx['i']].record())
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for i in range(10):
                     idx['i'] = i
-                    o = net(xs, None)
+                    o = net(xs, None, **nxt)
                     o['stage_02']['betas'].cpu() if i == 9 else None
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 h0.remove(); h1.remove()
-            bms = float(np.mean([a.elapsed_time(b_) for a, b_ in zip(ev0, ev1)]))
+            # pipelined: the events around the call see only the rest of a forward -> the step period
+            bms = dt / 10 * 1e3 if pipe else float(np.mean([a.elapsed_time(b_) for a, b_ in zip(ev0, ev1)]))
             if dtype == 'f32':
                 flop = executed_mfma_flop_per_image(net, size)
                 peak = F32_MFMA_PEAK_TFLOPS
@@ -604,7 +610,7 @@ def also_records(args, net, x):
                 peak = BF16_MFMA_PEAK_TFLOPS
             ach = flop * B / (bms * 1e-3) / 1e12
             rec = {'metric': baseline_metric(), 'value': B * 10 / dt, 'unit': 'images/sec',
-                   'ms_per_step': dt / 10 * 1e3, 'steps': 10, 'dtype': dtype,
+                   'ms_per_step': dt / 10 * 1e3, 'steps': 10, 'dtype': dtype, 'pipelined_batches': bool(pipe),
                    'workload': f'HRNet-W48 + regressor + SMPL-X + measurements, {size}x{size}, bs={B}, {dtype}',
                    'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                                 'frac': ach / peak, 'ms_per_launch_group': bms}}
@@ -675,9 +681,17 @@ def run_regressor(args, rank, world, local_rank):
     if not stub:
         betas_host = betas_host.pin_memory()
 
+    # software pipelining of consecutive batches (shapy_amd/models/backbone/prefetch.py): every step hands the
+    # NEXT batch (here: the same resident tensor) to the network, whose stem + layer1 then run under this
+    # batch's stage 4 / head / SMPL-X tail.  The last timed step prefetches too: the timed region holds exactly
+    # `steps` prologues and `steps` rests (the first step's prologue ran in the last warmup step, before the
+    # synchronize in front of the clock).  Outputs are bit-identical with --pipeline off.
+    pipelined = getattr(args, 'pipeline', 'on') == 'on' and not stub and not getattr(args, 'single_stream', False)
+    nxt = {'next_images': x} if pipelined else {}
+
     def step():
         with torch.no_grad():
-            out = net(x, None)
+            out = net(x, None, **nxt)
             betas_host.copy_(out['stage_02']['betas'], non_blocking=True)
             betas = gatherer(out['stage_02']['betas'])     # joined at the next call / wait()
         return out, betas
@@ -752,6 +766,12 @@ def run_regressor(args, rank, world, local_rank):
         return res, None
 
     backbone_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    call_ms = backbone_ms
+    if pipelined and net.backbone._prefetch.used:
+        # the events around the call bracket only the REST of a forward (its stem + layer1 ran on a side stream
+        # under the previous step): the roofline takes the whole step period instead -- an upper bound of
+        # the time the chip spends per backbone forward (it includes the regressor / SMPL-X tail)
+        backbone_ms = own_dt / args.steps * 1e3
     flop_img = conv_flop_per_image(net, args.size)
     algorithmic = flop_img * B / (backbone_ms * 1e-3) / 1e12
     # `achieved` = FLOPs the matrix cores EXECUTE / backbone time, so that frac <= 1 by
@@ -810,6 +830,7 @@ def run_regressor(args, rank, world, local_rank):
                    'global_batch': world * B, 'parallelism': f'dp{world}',
                    'multi_stream': not args.single_stream, 'conv_algo': algo,
                    'd2h_betas_in_timed_region': True,
+                   'pipelined_batches': bool(pipelined and net.backbone._prefetch.used),
                    'wino4_ksplit': {f'{c}@{t}': sl for (c, t), sl in net.backbone.ksplit_policy(B).items()},
                    'hip_graph': bool(net.backbone.use_graph is True or
                                      (net.backbone.use_graph == 'auto' and
@@ -826,6 +847,9 @@ def run_regressor(args, rank, world, local_rank):
                      'kernel': kernel + f', {n_launch} launches per backbone forward',
                      'flop_per_launch_group': exec_img * B,
                      'ms_per_launch_group': backbone_ms,
+                     'duration': ('step period (pipelined: the next batch\'s stem + layer1 run under this batch\'s '
+                                  f'head on a side stream; HIP events around the call see only the rest: {call_ms:.3f} ms)'
+                                  if backbone_ms != call_ms else 'HIP events around the backbone call'),
                      'achieved_counts': 'FLOPs issued to the matrix cores (direct layers: 2 x MAC; '
                                         'Winograd layers: 16 products per 2x2 tile / 36 per 4x4 tile '
                                         'and channel pair, whole tiles) / backbone time (HIP events)',
@@ -913,6 +937,9 @@ def main():
     ap.add_argument('--group-branches', default=None, choices=['auto', 'on', 'off'],
                     help='persistent grouped F(4x4) launches per depth level of a module '
                          '(HighResolutionNet.group_branches)')
+    ap.add_argument('--pipeline', default='on', choices=['on', 'off'],
+                    help="on (default): every step passes the next batch to the network (next_images=), whose stem + "
+                         "layer1 run under the current batch's head; off: one forward at a time")
     ap.add_argument('--no-also', action='store_true',
                     help='skip the `also` sub-records (the other BASELINE configurations, timed after '
                          'the headline\'s timed region in the default N = 1 run)')

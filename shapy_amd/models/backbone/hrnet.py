@@ -160,6 +160,7 @@ class HighResolutionModule(_Container):
         return self.num_inchannels
 
 
+from .prefetch import ProloguePrefetch, cut_of, ops_from
 from .plan import _Buf, _Plan  # noqa: E402,F401  (the op list, its ordering rules and the workspace packing)
 
 
@@ -316,6 +317,9 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: budget are demoted; 0 = off (default: the guard judges weights, not images)
         self.wino_guard_recheck_every = int(os.environ.get('SHAPY_WINO_GUARD_RECHECK', '0'))
         self._n_forward = 0
+        self._prefetch = ProloguePrefetch()
+        #: forward(x, prefetch=next_x): batches up to this size issue the next prologue BEFORE their own launches
+        self.prefetch_before_max_batch = 8
         self._capture_warned = False
         self.calibration_report = None
         self._calibrated_ver = None
@@ -433,9 +437,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
 
     def __getstate__(self):
         st = self.__dict__.copy()
-        st['_engine'] = {}
         st.pop('_xform_cache', None)
-        st['_ver_tensors'] = None
+        st['_engine'], st['_ver_tensors'], st['_prefetch'] = {}, None, ProloguePrefetch()
         return st
 
     _dag_eff = False
@@ -831,7 +834,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             blob = np.frombuffer(b''.join(P.wchunks), dtype=np.uint8)
             weights = torch.from_numpy(blob.copy()).to(device)
         eng = dict(ops=arr, n_ops=n, weights=weights, ws_per_img=ws_per_img, cnt_per_img=P.cnt_ints,
-                   plan=P, ws=None, graphs={},
+                   plan=P, ws=None, graphs={}, cut=cut_of(P) if self._dag_eff else 0,
                    feat_dim=P.ops[-1]['Cin'], esz=2 if bf16 else 4,
                    dtype={'f32': _lib.DTYPE_F32, 'bf16': _lib.DTYPE_BF16,
                           'f32x6': _lib.DTYPE_F32X6}[self.compute_dtype])
@@ -869,28 +872,25 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         x = x.contiguous().float()
         B, _, H, W = x.shape
         report = None
-        try:
-            for _ in range(3):
-                # the product's own engine (same plan key): the pass below runs its ops one at a
-                # time on the caller's stream, whatever lanes / groups / events the plan carries
-                eng = self._compile(H, W, x.device, graph=graph, B=B)
-                layers = self._calibrate_pass(lib, eng, x)
-                worst = {}
-                for name, algo, e_rms, e_max in layers:
-                    if e_rms > budget:
-                        worst[name] = 'winograd' if algo == 'winograd4' and winograd.eligible(
-                            3, 1, 1, *self._op_channels(eng, name)) else 'direct'
-                report = {'layers': layers, 'demoted': dict(self.layer_algo), 'budget': budget}
-                if not worst or not demote:
-                    break
-                for name, to in worst.items():
-                    e = next(l for l in layers if l[0] == name)
-                    log(f'Winograd guard: {name}: {e[1]} error {e[2]:.2e} rms-relative '
-                        f'(max {e[3]:.2e}) > budget {budget:.1e} on the probe batch -> {to}')
-                    self._guard_demote(name, to)
-                report['demoted'] = dict(self.layer_algo)
-        finally:
-            pass
+        for _ in range(3):
+            # the product's own engine (same plan key): the pass below runs its ops one at a
+            # time on the caller's stream, whatever lanes / groups / events the plan carries
+            eng = self._compile(H, W, x.device, graph=graph, B=B)
+            layers = self._calibrate_pass(lib, eng, x)
+            worst = {}
+            for name, algo, e_rms, e_max in layers:
+                if e_rms > budget:
+                    worst[name] = 'winograd' if algo == 'winograd4' and winograd.eligible(
+                        3, 1, 1, *self._op_channels(eng, name)) else 'direct'
+            report = {'layers': layers, 'demoted': dict(self.layer_algo), 'budget': budget}
+            if not worst or not demote:
+                break
+            for name, to in worst.items():
+                e = next(l for l in layers if l[0] == name)
+                log(f'Winograd guard: {name}: {e[1]} error {e[2]:.2e} rms-relative '
+                    f'(max {e[3]:.2e}) > budget {budget:.1e} on the probe batch -> {to}')
+                self._guard_demote(name, to)
+            report['demoted'] = dict(self.layer_algo)
         self.calibration_report = report
         self._calibrated_ver = self._weights_version()
         return report
@@ -977,7 +977,10 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             g = eng['graphs'][key] = _CapturedForward(lib, eng, B, H, W, x.device, self.multi_stream)
         return g(x)
 
-    def forward(self, x):
+    def forward(self, x, prefetch=None):
+        """``prefetch``: the NEXT batch (same shape, float32, contiguous, ready on the current stream): its stem +
+        layer1 run under this batch's stage 4 / head and the next ``forward(that tensor)`` skips them
+        (prefetch.py; bit-identical features)."""
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f'expected [B,3,H,W], got {tuple(x.shape)}')
         if self.training:
@@ -1016,21 +1019,37 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             return {'concat': self._forward_graph(lib, eng, x)}
         need = eng['ws_per_img'] * B * eng['esz']
         # one workspace (+ split-K counters) per CALLER stream: forwards issued on different streams
-        # (several batches in flight) must not share activations
+        # (several batches in flight) must not share activations; a second one for `prefetch=` (prefetch.py)
         if eng['ws'] is None:
             eng['ws'] = {}
         sk = torch.cuda.current_stream().cuda_stream
         ent = eng['ws'].get(sk)
-        if ent is None or ent[0].numel() < need or ent[2] < B:
-            ent = eng['ws'][sk] = (torch.empty(need, dtype=torch.uint8, device=x.device),
-                                   self._counters(eng, B, x.device), B)
+        if ent is None or ent['ws'][0].numel() < need or ent['B'] < B:
+            ent = eng['ws'][sk] = dict(ws=[torch.empty(need, dtype=torch.uint8, device=x.device), None],
+                                       cnt=self._counters(eng, B, x.device), B=B, cur=0)
         feat = torch.empty(B, eng['feat_dim'], dtype=torch.float32, device=x.device)
-        rc = lib.shapy_hrnet_run(eng['ops'], eng['n_ops'], _lib.ptr(eng['weights']), _lib.ptr(x),
-                                 _lib.ptr(ent[0]), eng['ws_per_img'], _lib.ptr(ent[1]), eng['cnt_per_img'],
-                                 _lib.ptr(feat), B, H, W, int(self.multi_stream), eng['dtype'],
-                                 _lib.current_stream())
+
+        def run(first, n, inp, ws, multi, stream):
+            return lib.shapy_hrnet_run(ops_from(eng, first), n, _lib.ptr(eng['weights']), _lib.ptr(inp), _lib.ptr(ws),
+                                       eng['ws_per_img'], _lib.ptr(ent['cnt']), eng['cnt_per_img'], _lib.ptr(feat),
+                                       B, H, W, multi, eng['dtype'], stream)
+        pf, first = self._prefetch.take(x, eng, ent, sk), 0
+        if pf is not None:                    # this batch's stem + layer1 ran under the previous batch
+            torch.cuda.current_stream().wait_event(pf['done'])
+            ent['cur'], first = pf['arena'], eng['cut']
+        ahead = (prefetch is not None and eng['cut'] > 0 and self.multi_stream and self._prefetch.usable(prefetch, x)
+                 and not torch.cuda.is_current_stream_capturing())
+        ev = self._prefetch.ready_event(ent) if ahead else None
+        rc = 0
+        if ahead and B <= self.prefetch_before_max_batch:
+            rc = self._prefetch.issue(lib, run, eng, ent, prefetch, ev, sk, need)
+        rc = rc or run(first, eng['n_ops'] - first, x, ent['ws'][ent['cur']], int(self.multi_stream),
+                       _lib.current_stream())
+        if not rc and ahead and B > self.prefetch_before_max_batch:
+            rc = self._prefetch.issue(lib, run, eng, ent, prefetch, ev, sk, need)
         if rc != 0:
             del eng['ws'][sk]         # a failed forward may leave arrival counters behind: start clean
+            self._prefetch.pending = None
         _lib.check(rc, 'shapy_hrnet_run')
         return {'concat': feat}
 

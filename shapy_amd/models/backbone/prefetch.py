@@ -1,0 +1,111 @@
+"""Software pipelining of consecutive batches: the NEXT batch's stem + layer1 under the CURRENT batch.
+
+`HighResolutionNet.forward(x, prefetch=next_x)` cuts the op list at its first barrier (transition1): the ops in
+front of it -- stem, conv2, the four Bottlenecks of layer1 -- are one HBM-bound chain on one lane, while stage 4
+and the head of the running batch are matrix-core work that leaves the memory system idle.  The prologue of
+`next_x` is issued on one of the executor's own side streams (no new stream: HIP multiplexes streams onto four
+hardware queues and a fifth one serialises the lanes) into a SECOND activation workspace;
+the next `forward(next_x)` finds it (same tensor, same version counter, same plan, same caller stream), waits
+for its event and runs only the rest of the op list.  Anything else -- another tensor, an in-place edit, a
+rebuilt plan -- is a full forward in the other workspace and the stale prologue is never looked at.
+
+Same kernels, same order per image: features are bit-identical with and without (tests/test_gpu_parity.py).
+Measured (profiles/r05o_prologue_prefetch_ab.txt, backbone only): float32 B = 64 12.45 -> 12.17 ms, bf16
+B = 32 3.72 -> 3.50 ms, float32 B = 8 3.86 -> 3.66 ms (issued BEFORE the rest there: a small batch leaves lane 3
+idle through stages 2-3; behind lane 3's own stage-4 work it would wait for the whole latency chain).
+"""
+import ctypes
+
+import torch
+
+from ... import _lib
+
+LANE = 3                 # the 4th branch's stream: idle until stage 4
+
+
+def cut_of(plan):
+    """Index of the first op of the 'rest' (the plan's first barrier), or 0 when the ops in front of it cannot
+    run as a self-contained serial prologue: a split-K layer among them (its arrival counters belong to the
+    caller's stream), or a later op that waits for one of their events (the prologue records none)."""
+    ops = plan.ops
+    cut = next((i for i, o in enumerate(ops) if o['barrier_before']), 0)
+    if cut <= 0:
+        return 0
+    sigs = {o['sig'] for o in ops[:cut] if o['sig'] >= 0}
+    if any(o.get('scrb') is not None or o.get('cnt_n', 0) for o in ops[:cut]):
+        return 0
+    for o in ops[cut:]:                      # (event slots are reused: a slot signalled again belongs to the rest)
+        if any(w in sigs for w in o['wait']):
+            return 0
+        sigs.discard(o['sig'])
+        if not sigs:
+            break
+    return cut
+
+
+def ops_from(eng, first):
+    if not first:
+        return eng['ops']
+    return ctypes.cast(ctypes.byref(eng['ops'], first * ctypes.sizeof(_lib.ShapyOp)),
+                       ctypes.POINTER(_lib.ShapyOp))
+
+
+class ProloguePrefetch:
+    """The stash of one network: at most one prologue in flight."""
+
+    def __init__(self):
+        self.pending = None
+        self._side = {}
+        self.issued = self.used = 0
+
+    def side_stream(self, lib, device):
+        s = self._side.get(device.index)
+        if s is None:
+            h = ctypes.c_void_p()
+            _lib.check(lib.shapy_hrnet_lane_stream(LANE, ctypes.byref(h)), 'shapy_hrnet_lane_stream')
+            s = self._side[device.index] = torch.cuda.ExternalStream(h.value, device=device)
+        return s
+
+    @staticmethod
+    def key(x, sk):
+        return (x.data_ptr(), tuple(x.shape), x._version, sk)
+
+    def take(self, x, eng, ent, sk):
+        """The stashed prologue of exactly this input, or None (the stash is dropped either way).  The stash holds
+        the tensor, the plan and the workspace entry themselves: none of their addresses can have been reused."""
+        pf, self.pending = self.pending, None
+        if pf is not None and pf['eng'] is eng and pf['ent'] is ent and pf['key'] == self.key(x, sk):
+            self.used += 1
+            return pf
+        return None
+
+    @staticmethod
+    def usable(nx, x):
+        return (torch.is_tensor(nx) and nx.is_cuda and nx.device == x.device and nx.dtype == torch.float32
+                and nx.shape == x.shape and nx.is_contiguous())
+
+    def ready_event(self, ent):
+        """Recorded on the caller's stream BEFORE the rest of the running batch is issued: the next input is
+        there and the other workspace's last user (the batch before this one) is done."""
+        if 'ev' not in ent:
+            ent['ev'] = torch.cuda.Event()
+        ent['ev'].record()
+        return ent['ev']
+
+    def issue(self, lib, run, eng, ent, nx, ev, sk, need):
+        other = 1 - ent['cur']
+        if ent['ws'][other] is None:
+            ent['ws'][other] = torch.empty(max(need, ent['ws'][0].numel()), dtype=torch.uint8, device=nx.device)
+            ent['done'] = [torch.cuda.Event(), torch.cuda.Event()]
+        side = self.side_stream(lib, nx.device)
+        side.wait_event(ev)
+        # the side stream reads / writes these after the caller may have dropped them
+        nx.record_stream(side)
+        ent['ws'][other].record_stream(side)
+        rc = run(0, eng['cut'], nx, ent['ws'][other], 0, ctypes.c_void_p(side.cuda_stream))
+        if rc != 0:
+            return rc
+        ent['done'][other].record(side)
+        self.pending = dict(key=self.key(nx, sk), eng=eng, ent=ent, arena=other, done=ent['done'][other], x=nx)
+        self.issued += 1
+        return 0

@@ -137,7 +137,9 @@ class HMRLikeRegressor(nn.Module):
             out[name] = param_tensor[:, a:b]
         return out
 
-    def compute_features(self, images, extra_features=None):
+    def compute_features(self, images, extra_features=None, next_images=None):
+        if next_images is not None:             # software pipelining of consecutive batches (backbone/prefetch.py)
+            return self.backbone(images, prefetch=next_images)[self.feature_key]
         return self.backbone(images)[self.feature_key]
 
     def _faces(self, device):
@@ -225,9 +227,11 @@ class HMRLikeRegressor(nn.Module):
         return param_dicts, rot_all[S - 1], coeffs, cam
 
     def forward(self, images, targets=None, compute_losses=True, cond=None, extra_features=None,
-                **kwargs):
+                next_images=None, **kwargs):
+        """``next_images`` (not in the reference): the NEXT batch of the loop, already on the device; its stem +
+        layer1 run under this batch's head (bit-identical outputs; backbone/prefetch.py)."""
         batch_size = len(images)
-        features = self.compute_features(images, extra_features=extra_features)
+        features = self.compute_features(images, extra_features=extra_features, next_images=next_images)
         regr_output = self.regressor(features, cond=cond, extra_features=extra_features)
         parameters = [regr_output] if torch.is_tensor(regr_output) else regr_output[0]
 

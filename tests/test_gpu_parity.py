@@ -836,6 +836,78 @@ def test_hrnet_event_driven_plan_equals_barrier_plan(network, B, size, graph):
     assert all(torch.equal(g, ref) for g in got)
 
 
+@pytest.mark.parametrize('B,size,cdt', [(3, 96, 'f32'), (12, 96, 'f32'), (64, 224, 'f32'), (12, 96, 'bf16')])
+def test_hrnet_prefetched_prologue_bit_identical(network, B, size, cdt):
+    """forward(x, prefetch=next_x): the next batch's stem + layer1 on a side stream in a second workspace
+    (backbone/prefetch.py).  Same kernels in the same order per image -> the features of a pipelined loop over
+    alternating inputs equal the plain forwards bit for bit; B <= 8 issues the prologue before the rest, larger
+    batches behind it.  A stash that does not match the next call (another tensor, an in-place edit) is ignored."""
+    from shapy_amd.models.backbone import hrnet as hrnet_mod
+    from shapy_amd.utils import synthetic as syn
+    bb = network.backbone
+    keep = bb.multi_stream, bb.compute_dtype
+    bb.multi_stream, bb.conv_algo, bb.compute_dtype = True, hrnet_mod.DEFAULT_CONV_ALGO, cdt
+    xs = [torch.from_numpy(syn.synthetic_images(B, size, 60 + i)).cuda() for i in range(3)]
+    try:
+        with torch.no_grad():
+            refs = [bb(x)['concat'].clone() for x in xs]
+            used0, issued0 = bb._prefetch.used, bb._prefetch.issued
+            got = []
+            for k in range(7):
+                got.append(bb(xs[k % 3], prefetch=xs[(k + 1) % 3])['concat'].clone())
+            assert bb._prefetch.issued - issued0 == 7 and bb._prefetch.used - used0 == 6
+            for k in range(7):
+                assert torch.equal(got[k], refs[k % 3]), k
+            # the stash (xs[1]) is not what comes next: full forward, right answer; the stash is dropped
+            assert torch.equal(bb(xs[2])['concat'], refs[2]) and bb._prefetch.pending is None
+            # an in-place edit between prefetch and use: the version counter differs -> full forward on the new data
+            y = xs[0].clone()
+            bb(xs[1], prefetch=y)
+            y.mul_(0.5)
+            used1 = bb._prefetch.used
+            edited = bb(y)['concat'].clone()
+            assert bb._prefetch.used == used1
+            assert torch.equal(edited, bb(y.clone())['concat'])
+            # a view of the same memory is the same input
+            bb(xs[1], prefetch=xs[0])
+            assert torch.equal(bb(xs[0][:])['concat'], refs[0]) and bb._prefetch.used == used1 + 1
+            # single-stream forwards and shapes that do not match ignore the argument
+            bb.multi_stream = False
+            issued1 = bb._prefetch.issued
+            assert torch.equal(bb(xs[0], prefetch=xs[1])['concat'], bb(xs[0])['concat'])
+            bb.multi_stream = True
+            assert torch.equal(bb(xs[0], prefetch=xs[1][:1])['concat'], refs[0]) and bb._prefetch.issued == issued1
+        torch.cuda.synchronize()
+    finally:
+        bb.multi_stream, bb.compute_dtype = keep
+        bb.conv_algo = 'direct'
+
+
+def test_full_forward_next_images_bit_identical(network):
+    """SMPLXRegressor.forward(images, next_images=...): every output of a pipelined loop equals the plain call's."""
+    from shapy_amd.models.backbone import hrnet as hrnet_mod
+    from shapy_amd.utils import synthetic as syn
+    bb = network.backbone
+    keep = bb.multi_stream
+    bb.multi_stream, bb.conv_algo = True, hrnet_mod.DEFAULT_CONV_ALGO
+    xs = [torch.from_numpy(syn.synthetic_images(16, 224, 70 + i)).cuda() for i in range(2)]
+    try:
+        with torch.no_grad():
+            refs = [network(x, None) for x in xs]
+            used0 = bb._prefetch.used
+            for k in range(4):
+                out = network(xs[k & 1], None, next_images=xs[(k + 1) & 1])
+                ref = refs[k & 1]
+                assert torch.equal(out['features'], ref['features'])
+                assert torch.equal(out['stage_02']['betas'], ref['stage_02']['betas'])
+                assert torch.equal(out['stage_02']['vertices'], ref['stage_02']['vertices'])
+            assert bb._prefetch.used - used0 == 3
+        torch.cuda.synchronize()
+    finally:
+        bb.multi_stream = keep
+        bb.conv_algo = 'direct'
+
+
 def test_hrnet_two_host_threads_on_two_streams_bit_identical(network):
     """Two host threads issue forwards concurrently, each on its own stream: the executor serialises
     the ENQUEUE of a forward (one process-wide lock around the whole issue incl. its event records /

@@ -207,6 +207,56 @@ def test_plan_orders_every_memory_hazard(hrnet, dag, group, ksplit):
     assert total * 4 / 1e6 < 20.0            # MB per 224x224 image: packing works (no reuse: 112 MB)
 
 
+@pytest.mark.parametrize('B', [1, 16, 64])
+def test_prologue_cut_is_self_contained(hrnet, B):
+    """forward(x, prefetch=): the ops in front of the plan's first barrier (stem, conv2, layer1) run as a serial
+    prologue in a workspace of their own (backbone/prefetch.py).  That is only valid when they read nothing but the
+    input and what they wrote themselves, hold no split-K scratch (its counters belong to the caller's stream) and
+    no op of the rest waits for one of their events -- for every batch bucket's plan."""
+    from shapy_amd.models.backbone.prefetch import ProloguePrefetch, cut_of
+    keep = hrnet._dag_eff, hrnet.conv_algo, hrnet.wino4_min_hw
+    try:
+        hrnet._dag_eff, hrnet.conv_algo, hrnet.wino4_min_hw = True, 'winograd4', 7
+        hrnet._ksplit_eff, hrnet._direct_ksplit_eff = hrnet.ksplit_policy(B), hrnet.direct_ksplit_policy(B, False)
+        P = hrnet._build_plan(224, 224)
+        P.sync_plan()
+        P.allocate()
+    finally:
+        hrnet._ksplit_eff = hrnet._direct_ksplit_eff = None
+        hrnet._dag_eff, hrnet.conv_algo, hrnet.wino4_min_hw = keep
+    cut = cut_of(P)
+    assert cut == 15 and P.ops[cut]['name'] == 'transition1.0' and P.ops[cut]['barrier_before']
+    written = set()
+    for o in P.ops[:cut]:
+        for key in ('inb', 'resb'):
+            assert o.get(key) is None or id(o[key]) in written, o.get('name')
+        assert o.get('scrb') is None
+        written.add(id(o['outb']))
+    # what the rest reads of the prologue is its last output only
+    last = P.ops[cut - 1]['outb']
+    for o in P.ops[cut:]:
+        for key in ('inb', 'resb'):
+            assert o.get(key) is None or id(o[key]) not in written or o[key] is last
+    # a prologue with a split-K layer, or a rest that waits for a prologue event, has no cut
+    P.ops[3]['cnt_n'] = 8
+    assert cut_of(P) == 0
+    P.ops[3]['cnt_n'] = 0
+    P.ops[cut + 1]['wait'] = [P.ops[1]['sig'], -1, -1]
+    assert P.ops[1]['sig'] >= 0 and cut_of(P) == 0
+    # the stash: same memory + same version + same plan + same workspace entry + same stream, else nothing
+    pf, eng, ent = ProloguePrefetch(), {}, {}
+    x = torch.zeros(2, 3, 32, 32)
+    pf.pending = dict(key=pf.key(x, 7), eng=eng, ent=ent, arena=1, done=None, x=x)
+    assert pf.take(x[:], eng, ent, 7)['arena'] == 1 and pf.pending is None and pf.used == 1
+    for other in (dict(x=x.clone()), dict(eng={}), dict(ent={}), dict(sk=8), dict(edit=True)):
+        pf.pending = dict(key=pf.key(x, 7), eng=eng, ent=ent, arena=1, done=None, x=x)
+        if other.get('edit'):
+            x.add_(1)
+        assert pf.take(other.get('x', x), other.get('eng', eng), other.get('ent', ent), other.get('sk', 7)) is None
+        assert pf.pending is None
+    assert pf.used == 1 and not pf.usable(x, x)            # (host tensors are never prefetched)
+
+
 @pytest.mark.parametrize('size', [64, 256])
 def test_event_driven_plan_at_other_input_sizes(hrnet, size):
     """The dependency events fit their 64 slots and at most three waits per op at the sizes the
