@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--dtype', default='f32')
+    ap.add_argument('--barrier', type=int, default=1, help='cut at the N-th barrier of the plan (1: transition1, 2: transition2)')
     ap.add_argument('--modes', default='base,product,split,before-3,after-3,after-1,before-2,base')
     args = ap.parse_args()
     lib = _lib.load()
@@ -43,9 +44,12 @@ def main():
     ref = [net(x)['concat'].clone() for x in xs]
     eng = net._compile(S, S, dev, graph=False, B=B)
     P = eng['plan']
-    cut = next(i for i, o in enumerate(P.ops) if o['barrier_before'])
-    sigs_before = {o['sig'] for o in P.ops[:cut] if o['sig'] >= 0}
-    assert not any(w in sigs_before for o in P.ops[cut:] for w in o['wait']), 'rest waits on a prologue event'
+    cut = [i for i, o in enumerate(P.ops) if o['barrier_before']][args.barrier - 1]
+    live = {o['sig'] for o in P.ops[:cut] if o['sig'] >= 0}
+    for o in P.ops[cut:]:                    # (event slots are reused: a slot signalled again belongs to the rest)
+        assert not any(w in live for w in o['wait']), 'the rest waits for a prologue event'
+        live.discard(o['sig'])
+    assert not any(o.get('scrb') is not None for o in P.ops[:cut]), 'split-K layer in the prologue'
     print(f'# cut at op {cut} ({P.ops[cut].get("name")}): prologue {cut} ops, rest {eng["n_ops"] - cut}')
     need = eng['ws_per_img'] * B * eng['esz']
     arenas = [torch.empty(need, dtype=torch.uint8, device=dev) for _ in range(2)]
