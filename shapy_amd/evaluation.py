@@ -140,9 +140,18 @@ class Evaluator(object):
         metric means in mm (identical on every rank)."""
         model.eval()
         metric_values = defaultdict(list)
-        for images, targets in batches:
-            images = images.to(device=device)
-            model_output = model(images, targets, device=device)
+        # one batch of lookahead: the next batch is uploaded before this one runs, and a network that can use it
+        # (SMPLXRegressor: accepts_next_images) runs its stem + layer1 under this batch's head (bit-identical
+        # outputs; models/backbone/prefetch.py)
+        it = iter(batches)
+        ahead = getattr(model, 'accepts_next_images', False)
+        nxt = next(it, None)
+        nxt = None if nxt is None else (nxt[0].to(device=device), nxt[1])
+        while nxt is not None:
+            (images, targets), nxt = nxt, next(it, None)
+            nxt = None if nxt is None else (nxt[0].to(device=device), nxt[1])
+            extra = {'next_images': nxt[0]} if ahead and nxt is not None else {}
+            model_output = model(images, targets, device=device, **extra)
             num_stages = model_output.get('num_stages', 1)
             stage_n_out = model_output.get(f'stage_{num_stages - 1:02d}', {})
             cur = self.compute_metric(

@@ -137,6 +137,8 @@ class HMRLikeRegressor(nn.Module):
             out[name] = param_tensor[:, a:b]
         return out
 
+    accepts_next_images = True       # forward(..., next_images=): evaluation.Evaluator.run looks one batch ahead
+
     def compute_features(self, images, extra_features=None, next_images=None):
         if next_images is not None:             # software pipelining of consecutive batches (backbone/prefetch.py)
             return self.backbone(images, prefetch=next_images)[self.feature_key]
