@@ -64,15 +64,18 @@ def baseline_metric():
         return 'images/sec whole-node (HRNet+SMPL-X fwd), 224×224 bs=64; betas L2 vs CPU'
 
 
-def _f32_plan(net, size):
+def _f32_plan(net, size, batch=None):
     """The backbone's float32 op list at this size: the compiled engine's own plan when the run
     is float32 (the engine of the CURRENT layer_algo: the Winograd guard may have rebuilt the plan
-    after demoting layers), a freshly built one otherwise (the bf16 / f32x6 plans pad channels)."""
+    after demoting layers; of the batch bucket that takes / does not take the bf16x6 head GEMMs), a freshly
+    built one otherwise (the bf16 / f32x6 plans pad channels)."""
     bb = net.backbone
     cur = tuple(sorted(getattr(bb, 'layer_algo', {}).items()))
+    x6 = None if batch is None else 0 < getattr(bb, 'x6_gemm_min_batch', 0) <= batch
     best = None
     for key, eng in bb._engine.items():
-        if key[0] == size and key[1] == size and key[3] == 'f32' and key[4] == bb.conv_algo:
+        if key[0] == size and key[1] == size and key[3] == 'f32' and key[4] == bb.conv_algo \
+                and (x6 is None or key[13] == x6):
             if cur in key:
                 return eng['plan']
             best = eng['plan']
@@ -99,13 +102,22 @@ def conv_flop_per_image(net, size, plan=None):
     return 2 * macs
 
 
-def executed_mfma_flop_per_image(net, size, plan=None):
+#: a layer on the bf16x6 kernel issues 6 bf16 MFMAs per float32 multiply-add; the matrix-pipe TIME it needs, in
+#: FLOPs of the f32 pipe: 6 x (f32 peak / bf16 peak) per FLOP
+X6_F32_PIPE_EQUIV = 6.0 * F32_MFMA_PEAK_TFLOPS / BF16_MFMA_PEAK_TFLOPS
+
+
+def executed_mfma_flop_per_image(net, size, plan=None, batch=None, parts=False):
     """FLOPs the matrix cores actually execute per image with the backbone's conv_algo: direct
     layers as counted above, Winograd F(2x2,3x3) layers 16 products per 2x2 tile and channel pair,
-    F(4x4,3x3) layers 36 per 4x4 tile (whole tiles: partly filled edge tiles count in full)."""
+    F(4x4,3x3) layers 36 per 4x4 tile (whole tiles: partly filled edge tiles count in full).  Layers on the
+    bf16x6 kernel (SHAPY_TILE_X6: the head's wide 1x1 GEMMs from bs 64) run on the bf16 matrix cores: they count
+    with the matrix-pipe time they need, expressed in f32-pipe FLOPs (x 0.3775), so that
+    achieved / f32 peak stays "least matrix-pipe time / measured time" <= 1.  parts: (f32-core FLOPs, bf16-core
+    FLOPs of the x6 layers) instead."""
     from shapy_amd import _lib
-    plan = plan or _f32_plan(net, size)
-    macs = 0
+    plan = plan or _f32_plan(net, size, batch)
+    macs = macs_x6 = 0
     for o in plan.ops:
         if o['type'] not in (0, 1):
             continue
@@ -114,9 +126,13 @@ def executed_mfma_flop_per_image(net, size, plan=None):
             macs += 36 * -(-o['Ho'] // 4) * -(-o['Wo'] // 4) * cc
         elif o.get('wino_off', -1) >= 0:
             macs += 16 * -(-o['Ho'] // 2) * -(-o['Wo'] // 2) * cc
+        elif o['tile'] & _lib.TILE_X6:
+            macs_x6 += o['Ho'] * o['Wo'] * cc * o['ksize'] ** 2
         else:
             macs += o['Ho'] * o['Wo'] * cc * o['ksize'] ** 2
-    return 2 * macs
+    if parts:
+        return 2 * macs, 12 * macs_x6
+    return 2 * macs + 2 * macs_x6 * X6_F32_PIPE_EQUIV
 
 
 def pmc_traffic(batch, size, dtype='f32', algo='direct', any_algo=False):
@@ -571,10 +587,15 @@ def also_records(args, net, x):
     bb = net.backbone
     keep = bb.compute_dtype
     pipe_on = getattr(args, 'pipeline', 'on') == 'on' and not getattr(args, 'single_stream', False)
-    for tag, dtype, B, size, pipe in (('configs2_bf16_b32_per_gpu_shard', 'bf16', 32, args.size, pipe_on),
-                                      ('f32_256x256_reference_default_crop', 'f32', args.batch, 256, pipe_on),
-                                      ('headline_one_forward_at_a_time', args.dtype, args.batch, args.size, False)):
-        if tag.startswith('headline') and not pipe_on:
+    keep_x6 = bb.x6_gemm_min_batch
+    for tag, dtype, B, size, pipe, x6min in (
+            ('configs2_bf16_b32_per_gpu_shard', 'bf16', 32, args.size, pipe_on, keep_x6),
+            ('f32_256x256_reference_default_crop', 'f32', args.batch, 256, pipe_on, keep_x6),
+            ('headline_one_forward_at_a_time', args.dtype, args.batch, args.size, False, keep_x6),
+            # opt-in arithmetic (--head-gemm bf16x6): the head's wide 1x1 GEMMs on the bf16 matrix cores
+            ('headline_with_head_gemms_on_bf16x6', 'f32', args.batch, args.size, pipe_on, args.batch)):
+        if (tag == 'headline_one_forward_at_a_time' and not pipe_on) or \
+                (tag == 'headline_with_head_gemms_on_bf16x6' and (args.dtype != 'f32' or keep_x6)):
             continue
         try:
             from shapy_amd.utils import synthetic as syn
@@ -582,9 +603,9 @@ def also_records(args, net, x):
                 syn.synthetic_images(B, size, 100)).cuda()
             nxt = {'next_images': xs} if pipe else {}
             with torch.no_grad():
-                bb.compute_dtype = 'f32'
-                ref = net(xs, None) if dtype != 'f32' else None
-                bb.compute_dtype = dtype
+                bb.compute_dtype, bb.x6_gemm_min_batch = 'f32', keep_x6
+                ref = net(xs, None) if dtype != 'f32' or x6min != keep_x6 else None
+                bb.compute_dtype, bb.x6_gemm_min_batch = dtype, x6min
                 for _ in range(3):
                     o = net(xs, None, **nxt)
                 ev0, ev1 = hip_events(10)
@@ -603,7 +624,7 @@ def also_records(args, net, x):
             # pipelined: the events around the call see only the rest of a forward -> the step period
             bms = dt / 10 * 1e3 if pipe else float(np.mean([a.elapsed_time(b_) for a, b_ in zip(ev0, ev1)]))
             if dtype == 'f32':
-                flop = executed_mfma_flop_per_image(net, size)
+                flop = executed_mfma_flop_per_image(net, size, batch=B)
                 peak = F32_MFMA_PEAK_TFLOPS
             else:
                 flop = conv_flop_per_image(net, size)
@@ -611,13 +632,14 @@ def also_records(args, net, x):
             ach = flop * B / (bms * 1e-3) / 1e12
             rec = {'metric': baseline_metric(), 'value': B * 10 / dt, 'unit': 'images/sec',
                    'ms_per_step': dt / 10 * 1e3, 'steps': 10, 'dtype': dtype, 'pipelined_batches': bool(pipe),
-                   'workload': f'HRNet-W48 + regressor + SMPL-X + measurements, {size}x{size}, bs={B}, {dtype}',
+                   'workload': f'HRNet-W48 + regressor + SMPL-X + measurements, {size}x{size}, bs={B}, {dtype}' + (
+                       ', head 1x1 GEMMs on the bf16x6 kernel' if x6min != keep_x6 else ''),
                    'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                                 'frac': ach / peak, 'ms_per_launch_group': bms}}
             if ref is not None:
                 rec['parity'] = {
-                    'reference': 'the float32 HIP forward of the same images (bf16 error, reported '
-                                 'separately: the f32 path is the parity path)',
+                    'reference': 'the float32 HIP forward of the same images (the f32 path is the parity path; this '
+                                 'is the arithmetic mode\'s own error on top of it)',
                     'features_maxabs': float((o['features'].float() - ref['features']).abs().max()),
                     'betas_maxabs': float((o['stage_02']['betas'].float() -
                                            ref['stage_02']['betas']).abs().max())}
@@ -625,7 +647,7 @@ def also_records(args, net, x):
         except Exception as e:
             out[tag] = {'error': repr(e)}
         finally:
-            bb.compute_dtype = keep
+            bb.compute_dtype, bb.x6_gemm_min_batch = keep, keep_x6
     return out
 
 
@@ -649,6 +671,8 @@ def run_regressor(args, rank, world, local_rank):
                                  else '/tmp/shapy_synth_models')
         net.backbone.multi_stream = not args.single_stream
         net.backbone.compute_dtype = args.dtype
+        if getattr(args, 'head_gemm', 'f32') == 'bf16x6':
+            net.backbone.x6_gemm_min_batch = args.batch
         net.backbone.use_graph = {'auto': 'auto', 'on': True, 'off': False}[args.graph]
         if args.algo:
             net.backbone.conv_algo = args.algo
@@ -778,7 +802,8 @@ def run_regressor(args, rank, world, local_rank):
     # construction: the Winograd layers execute 2.25x (F(2x2)) / 4x (F(4x4)) fewer multiplies than
     # the direct convolution they compute.  The direct-convolution-equivalent rate (SURVEY.md 8d:
     # 36.933 GFLOP per image) is reported next to it as `algorithmic_equiv_tflops`.
-    exec_img = executed_mfma_flop_per_image(net, args.size) if args.dtype == 'f32' else flop_img
+    exec_img = executed_mfma_flop_per_image(net, args.size, batch=B) if args.dtype == 'f32' else flop_img
+    x6_parts = executed_mfma_flop_per_image(net, args.size, batch=B, parts=True) if args.dtype == 'f32' else None
     achieved = exec_img * B / (backbone_ms * 1e-3) / 1e12
     # f32x6 issues 6 bf16 MFMAs per float32 multiply-add: its matrix-core roof in algorithmic
     # (float32) FLOP/s is the dense bf16 peak / 6
@@ -798,7 +823,7 @@ def run_regressor(args, rank, world, local_rank):
     # HBM bytes per launch group (one backbone forward) from the committed PMC passes, gfx950
     # FETCH x2 correction applied
     traffic = pmc_traffic(B, args.size, args.dtype, algo)
-    n_launch = launches_per_forward(_f32_plan(net, args.size) if args.dtype == 'f32' else
+    n_launch = launches_per_forward(_f32_plan(net, args.size, B) if args.dtype == 'f32' else
                                     next(iter(net.backbone._engine.values()))['plan'])
     traffic_other = None
     if traffic is None:      # no PMC pass of THIS algorithm yet: `traffic` stays null; the last
@@ -831,6 +856,8 @@ def run_regressor(args, rank, world, local_rank):
                    'multi_stream': not args.single_stream, 'conv_algo': algo,
                    'd2h_betas_in_timed_region': True,
                    'pipelined_batches': bool(pipelined and net.backbone._prefetch.used),
+                   'head_gemm_arithmetic': ('bf16x6 (float32 tensors, exact 3-way bf16 split, f32 accumulate)'
+                                            if x6_parts and x6_parts[1] else 'f32 MFMA'),
                    'wino4_ksplit': {f'{c}@{t}': sl for (c, t), sl in net.backbone.ksplit_policy(B).items()},
                    'hip_graph': bool(net.backbone.use_graph is True or
                                      (net.backbone.use_graph == 'auto' and
@@ -846,6 +873,14 @@ def run_regressor(args, rank, world, local_rank):
                                              'f32x6': 2495.0 / 6.0}[args.dtype],   # MI355X_MICROARCH.md
                      'kernel': kernel + f', {n_launch} launches per backbone forward',
                      'flop_per_launch_group': exec_img * B,
+                     'bf16x6_layers': None if not (x6_parts and x6_parts[1]) else {
+                         'f32_core_flop_per_launch_group': x6_parts[0] * B,
+                         'bf16_core_flop_per_launch_group': x6_parts[1] * B,
+                         'note': 'the head\'s wide 1x1 GEMMs (Cin, Cout >= 512) run on the bf16 matrix cores: float32 '
+                                 'tensors, products from the exact 3-way bf16 split (6 MFMAs per product, f32 '
+                                 'accumulate; same kernel-test tolerance as the f32 kernel).  In `achieved` they '
+                                 f'count with the matrix-pipe time they need: bf16 FLOPs x f32 peak / bf16 peak '
+                                 f'(= {X6_F32_PIPE_EQUIV:.4f} per float32 FLOP)'},
                      'ms_per_launch_group': backbone_ms,
                      'duration': ('step period (pipelined: the next batch\'s stem + layer1 run under this batch\'s '
                                   f'head on a side stream; HIP events around the call see only the rest: {call_ms:.3f} ms)'
@@ -940,6 +975,10 @@ def main():
     ap.add_argument('--pipeline', default='on', choices=['on', 'off'],
                     help="on (default): every step passes the next batch to the network (next_images=), whose stem + "
                          "layer1 run under the current batch's head; off: one forward at a time")
+    ap.add_argument('--head-gemm', default='f32', choices=['f32', 'bf16x6'],
+                    help='bf16x6: the head\'s wide 1x1 GEMMs (Cin, Cout >= 512) on the bf16 matrix cores -- float32 '
+                         'tensors, exact 3-way bf16 split, f32 accumulate (opt-in; the default run reports it as an '
+                         '`also` record)')
     ap.add_argument('--no-also', action='store_true',
                     help='skip the `also` sub-records (the other BASELINE configurations, timed after '
                          'the headline\'s timed region in the default N = 1 run)')

@@ -140,6 +140,10 @@ typedef struct ShapyConv {
 #define SHAPY_TILE_WINO4 0x100000
 #define SHAPY_TILE_KSPLIT(s) ((((s) - 1) & 3) << 21)
 #define SHAPY_TILE_W4_KSPLIT(s) SHAPY_TILE_KSPLIT(s)
+/* In a FLOAT32 op list (ShapyOp.tile): this layer's weights are the three bf16 planes [Cout][3][Kp] of the exact
+ * 3-way split and its products come from the bf16 matrix cores (the arithmetic SHAPY_DTYPE_F32X6 selects for a
+ * whole plan; tensors stay float32).  A direct shapy_conv2d call says the same with ShapyConv.dtype. */
+#define SHAPY_TILE_X6 0x800000
 
 int shapy_conv2d(const ShapyConv *desc_host, void *stream);
 

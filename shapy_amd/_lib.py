@@ -71,6 +71,7 @@ for _k, _v in list(TILES.items()):      # tuning knobs (csrc/conv_igemm.hip: con
     TILES[_k + '+pd3'] = _v | 0x40000         # implicit GEMM: 3 chunks of loads in flight (bf16 default)
     TILES[_k + '+pd1'] = _v | 0x80000         # ... 1 chunk (float32 default)
     TILES[_k + '+noallk'] = _v | 0x20000      # Winograd: K loop chunk by chunk even for Cin = 48 / 64
+TILE_X6 = 0x800000                      # in a float32 op list: this layer on the bf16x6 kernel (split weight planes)
 TILE_WINO4 = 0x100000                   # ShapyConv.wgt_wino holds F(4x4,3x3) filters (conv_wino4.hip)
 
 

@@ -418,7 +418,11 @@ int conv_tile_auto_x6(int M, int Cout, int K) {
   // (48 / 64 / 96) with the least padding; on a tie the 96-wide tile (wave tile 32x48) wins
   // while M keeps >= 196 M-tiles busy, the 48-wide one below that; deep-K wide layers of the
   // head take 128x64.
+  // Round 5 (profiles/r05q_head_gemm_x6_vs_f32.txt, M = 3,136): the wide GEMMs of the head take 128x128 (wave
+  // tile 64x64: 24 fragment reads per 96 MFMAs) -- 2048 -> 2048 161 us against 227 (128x64) and 253 for the f32
+  // kernel, 1536 -> 2048 123 / 179 / 196, 512 -> 2048 56 / 69 / 71.
   const int p48 = (Cout + 47) / 48 * 48, p64 = (Cout + 63) / 64 * 64, p96 = (Cout + 95) / 96 * 96;
+  if (Cout >= 1024 && Cout % 128 == 0 && K >= 512 && M >= 2048) return SHAPY_TILE_128x128;
   if (p64 < p48 && p64 <= p96) return (Cout >= 1024 && K >= 1024) ? SHAPY_TILE_128x64 : SHAPY_TILE_64x64;
   if (p96 <= p48 && p96 <= p64 && M >= 8192) return SHAPY_TILE_64x96;
   return p48 <= p64 ? SHAPY_TILE_64x48 : SHAPY_TILE_64x64;

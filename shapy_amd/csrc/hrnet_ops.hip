@@ -298,7 +298,8 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
       d.in = buf(q.in_off);
       d.wgt = (const char *)weights + q.wgt_off * esz;
       d.bias = q.bias_off >= 0 ? wf32 + q.bias_off : nullptr;
-      d.dtype = dtype;
+      // a float32 plan may hold single layers in the bf16x6 arithmetic (their weights are split planes)
+      d.dtype = (dtype == SHAPY_DTYPE_F32 && (q.tile & SHAPY_TILE_X6)) ? SHAPY_DTYPE_F32X6 : dtype;
       d.res = buf(q.res_off);
       d.out = buf(q.out_off);
       d.B = B; d.Hi = q.Hi; d.Wi = q.Wi; d.Cin = q.Cin; d.in_ld = q.in_ld;
@@ -307,7 +308,7 @@ int hrnet_run(const ShapyOp *ops, int n_ops, const void *weights, const float *i
       d.res_coff = q.res_coff; d.relu = q.relu; d.ups = q.ups; d.tile = q.tile;
       d.split_kib = 0;
       d.split_cnt_n = 0;
-      d.wgt_wino = (dtype == SHAPY_DTYPE_F32 && q.wino_off >= 0) ? wf32 + q.wino_off : nullptr;
+      d.wgt_wino = (d.dtype == SHAPY_DTYPE_F32 && q.wino_off >= 0) ? wf32 + q.wino_off : nullptr;
       // split-K layers: slab in the workspace, arrival counters in the caller's counter array
       d.split_ws = buf(q.split_off);
       if (d.split_ws && q.split_floats > 0 && q.split_off + q.split_floats <= ws_per_img) {

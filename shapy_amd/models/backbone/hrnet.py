@@ -232,29 +232,27 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.multi_stream = True
         self.tile_overrides = {}
         self.tile_flags = 0          # OR-ed into every conv's tile id (tuning knobs)
-        #: replay the forward as one hipGraph (csrc/capi.hip) instead of ~330 launches: True (the
-        #: captured barrier plan), False, or 'auto' = True for batches up to graph_max_batch
+        #: replay the forward as one hipGraph (csrc/capi.hip): True (the captured barrier plan), False, or 'auto' =
+        #: True for batches up to graph_max_batch = 0, i.e. never: the eager event-driven forward is faster than the
+        #: replay at every batch size (B = 1: 5.5 vs 6.3 ms, B = 64: 12.8 vs 14.0)
         self.use_graph = 'auto'
-        #: round 3: 0 = 'auto' never captures -- with the event-driven plan and lane priorities the
-        #: eager forward is faster than the replay at every batch size (B = 1: 5.5 vs 6.3 ms, B = 8:
-        #: 6.1 vs 7.4, B = 64: 12.8 vs 14.0; run AC) -- set use_graph = True to replay anyway
         self.graph_max_batch = 0
         #: 'f32' = exact-f32 MFMA (parity path); 'f32x6' = float32 storage, products from the
         #: exact 3-way bf16 split on the bf16 matrix cores (float32-class accuracy);
         #: 'bf16' = bf16 weights/activations, f32 accumulate
         self.compute_dtype = 'f32'
-        #: float32 convolution algorithm of the 3x3 / stride-1 layers (float32-class results, same
-        #: 1e-4 parity tests for all of them):
-        #:   'winograd4' (default) = Winograd F(4x4,3x3) (csrc/conv_wino4.hip: 36 multiplies per
-        #:       4x4 outputs, 48-channel N tiles) on maps of at least wino4_min_hw pixels a side,
-        #:       F(2x2,3x3) on the rest
-        #:   'winograd' = Winograd F(2x2,3x3) (csrc/conv_wino.hip, 2.25x fewer MFMAs than direct)
-        #:       wherever the kernel applies
-        #:   'direct' = implicit GEMM for every layer (the exact-f32 fmaf chain of the reference's
-        #:       sum order)
+        #: opt-in (0 = never, the default): in 'f32' forwards of at least this many images the head's wide 1x1 GEMMs
+        #: (Cin, Cout >= 512) take the bf16x6 arithmetic layer by layer (SHAPY_TILE_X6) -- 2048 -> 2048 at M = 3,136:
+        #: 161 vs 253 us, bs 64 +2.3 % (profiles/r05q_*); the default keeps every f32 product on the f32 matrix cores
+        self.x6_gemm_min_batch = int(os.environ.get('SHAPY_X6_GEMM_MIN_BATCH', '0'))
+        self._x6_eff = False
+        #: float32 convolution algorithm of the 3x3 / stride-1 layers (float32-class results, same 1e-4 parity tests):
+        #:   'winograd4' (default) = Winograd F(4x4,3x3) (csrc/conv_wino4.hip: 36 multiplies per 4x4 outputs, 48-channel
+        #:       N tiles) on maps of at least wino4_min_hw pixels a side, F(2x2,3x3) on the rest
+        #:   'winograd' = F(2x2,3x3) (csrc/conv_wino.hip, 2.25x fewer MFMAs than direct) wherever the kernel applies
+        #:   'direct' = implicit GEMM for every layer (the exact-f32 fmaf chain of the reference's sum order)
         #:   'auto' = F(2x2) only on maps of at least wino_min_hw pixels a side
-        #: (SHAPY_CONV_ALGO / SHAPY_WINO4_MIN_HW override the defaults: A/B runs of whole test
-        #: suites and benches under another default without editing code)
+        #: (SHAPY_CONV_ALGO / SHAPY_WINO4_MIN_HW override the defaults for A/B runs of whole suites and benches)
         self.conv_algo = os.environ.get('SHAPY_CONV_ALGO', DEFAULT_CONV_ALGO)
         self.wino_min_hw = 14
         self.wino4_min_hw = int(os.environ.get('SHAPY_WINO4_MIN_HW', DEFAULT_WINO4_MIN_HW))
@@ -570,6 +568,9 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                     scrb = P.buf(1, 1, slab * (2 if bf16 else 1))    # float32 partials in a bf16-element arena
                     cnt_off, P.cnt_ints = P.cnt_ints, P.cnt_ints + cnt_n
                     wino_flag |= _lib.tile_w4_ksplit(sl)
+            lx6 = (self._x6_eff and not (bf16 or x6) and wino_off < 0 and scrb is None and ks == 1 and st == 1
+                   and ups == 1 and cin_p >= 512 and cout_p >= 512 and cin_p % 32 == 0)
+            wino_flag |= _lib.TILE_X6 if lx6 else 0
             P.op(type=_lib.OP_CONV, lane=lane, inb=inb, outb=outb, resb=res, scrb=scrb, cnt_off=cnt_off,
                  cnt_n=cnt_n,
                  Hi=Hi, Wi=Wi, Cin=cin_p,
@@ -578,7 +579,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                  res_ld=(res_ld or (res.C if res is not None else 0)), res_coff=res_coff,
                  relu=int(relu), ups=ups,
                  tile=_lib.TILES[ov.get(name, 'auto')] | self.tile_flags | wino_flag,
-                 wgt_off=P.add_conv_weights(w), bias_off=P.add_weights(b), wino_off=wino_off,
+                 wgt_off=P.add_conv_weights(w, x6=lx6), bias_off=P.add_weights(b), wino_off=wino_off,
                  name=name, group=group)
             return outb, Ho, Wo
 
@@ -782,8 +783,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         return P
 
     def _compile(self, H, W, device, graph=False, B=None):
-        # event-driven plan: eager multi-stream forwards only (capturing it into a hipGraph segfaults
-        # inside graph creation on ROCm 7.2; the captured plan keeps the barrier form)
+        # event-driven plan: eager multi-stream forwards only (the captured hipGraph keeps the barrier form)
         self._dag_eff = bool(self.dag and self.multi_stream and not graph)
         if self.compute_dtype not in ('f32', 'f32x6', 'bf16'):
             raise ValueError(f'unknown compute_dtype {self.compute_dtype!r}')
@@ -798,15 +798,18 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                  self.wino4_min_hw, self._group_on(), self._dag_eff, tuple(self.wino4_n64),
                  tuple(sorted(self.layer_algo.items())), self.tile_flags,
                  tuple(sorted(self.tile_overrides.items())))
+        lx6 = self.compute_dtype == 'f32' and 0 < self.x6_gemm_min_batch <= (B or 0)
+        key_w += (lx6,)
         key = key_w + (tuple(sorted(pol.items())) + tuple(sorted(dpol.items())),)
         eng = self._engine.get(key)
         if eng is not None:
             return eng
-        self._ksplit_eff, self._direct_ksplit_eff = pol, dpol
+        self._ksplit_eff, self._direct_ksplit_eff, self._x6_eff = pol, dpol, lx6
         try:
             P = self._build_plan(H, W, bf16, self.compute_dtype == 'f32x6')
         finally:
             self._ksplit_eff = self._direct_ksplit_eff = None
+            self._x6_eff = False
         P.sync_plan()
         ws_per_img = P.allocate()
         n = len(P.ops)
@@ -978,9 +981,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         return g(x)
 
     def forward(self, x, prefetch=None):
-        """``prefetch``: the NEXT batch (same shape, float32, contiguous, ready on the current stream): its stem +
-        layer1 run under this batch's stage 4 / head and the next ``forward(that tensor)`` skips them
-        (prefetch.py; bit-identical features)."""
+        """``prefetch``: the NEXT batch (same shape, float32, contiguous, ready on the current stream): its stem + layer1
+        run under this batch's head and the next ``forward(that tensor)`` skips them (prefetch.py; bit-identical)."""
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f'expected [B,3,H,W], got {tuple(x.shape)}')
         if self.training:

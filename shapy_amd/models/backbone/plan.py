@@ -63,10 +63,10 @@ class _Plan:
         self.wbytes += len(raw)
         return off
 
-    def add_conv_weights(self, w):
-        """OHWI conv weights in the layout of the plan's arithmetic; offset in elements of the
-        activation type (float32 words for f32 / f32x6, bfloat16 for bf16)."""
-        if not self.x6:
+    def add_conv_weights(self, w, x6=False):
+        """OHWI conv weights in the layout of the plan's arithmetic (x6: of this layer's, in a float32 plan);
+        offset in elements of the activation type (float32 words for f32 / f32x6, bfloat16 for bf16)."""
+        if not (self.x6 or x6):
             return self.add_weights(w, as_bf16=self.bf16)
         from ...utils.split import split_bf16x3
         w = np.ascontiguousarray(w, np.float32)

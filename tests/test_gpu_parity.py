@@ -450,6 +450,8 @@ X6_CASES = [c for c in CONV_CASES if c[10] in (0, 5, 8, 2, 6, 3, 7)] + [
     (1, 8, 8, 4, 16, 1, 1, 1, False, False, 0),       # a single 4-wide K chunk
     (2, 12, 12, 48, 96, 3, 2, 1, False, True, 9),     # 128x48, stride 2
     (2, 12, 12, 64, 64, 3, 1, 1, True, True, 10),     # 128x64
+    (4, 7, 7, 512, 1024, 1, 1, 1, True, True, 3),     # 128x128: the head's wide 1x1 GEMMs (partial M tile)
+    (43, 7, 7, 512, 1024, 1, 1, 1, False, True, 0),   # ... chosen automatically from M = 2,048 on
 ]
 
 
@@ -906,6 +908,36 @@ def test_full_forward_next_images_bit_identical(network):
     finally:
         bb.multi_stream = keep
         bb.conv_algo = 'direct'
+
+
+def test_hrnet_head_gemms_on_bf16x6_vs_f32_kernel(network):
+    """Opt-in (x6_gemm_min_batch = 64): the head's fifteen wide 1x1 GEMMs on the bf16 matrix cores
+    (SHAPY_TILE_X6 in a float32 plan: float32 tensors, exact 3-way bf16 split, f32 accumulate).  Against the
+    all-f32-MFMA plan of the same batch the features move by float32 rounding only."""
+    from shapy_amd import _lib
+    from shapy_amd.models.backbone import hrnet as hrnet_mod
+    from shapy_amd.utils import synthetic as syn
+    bb = network.backbone
+    keep = bb.multi_stream, bb.x6_gemm_min_batch
+    bb.multi_stream, bb.conv_algo = True, hrnet_mod.DEFAULT_CONV_ALGO
+    x = torch.from_numpy(syn.synthetic_images(64, 224, 77)).cuda()
+    try:
+        with torch.no_grad():
+            bb.x6_gemm_min_batch = 0
+            f32 = bb(x)['concat'].clone()
+            bb.x6_gemm_min_batch = 64
+            mixed = bb(x)['concat'].clone()
+            small = bb(x[:8])['concat'].clone()            # a smaller batch keeps the f32 kernel ...
+            bb.x6_gemm_min_batch = 0
+            assert torch.equal(small, bb(x[:8])['concat'])  # ... bit for bit
+        plans = [e['plan'] for k, e in bb._engine.items() if k[0] == 224 and k[13] is True]
+        assert plans and sum(1 for o in plans[-1].ops if o['tile'] & _lib.TILE_X6) == 15
+    finally:
+        bb.multi_stream, bb.x6_gemm_min_batch = keep
+        bb.conv_algo = 'direct'
+    scale = f32.abs().max().item()
+    err = (mixed - f32).abs().max().item()
+    assert 0 < err < 2e-5 * max(1.0, scale), (err, scale)
 
 
 def test_hrnet_two_host_threads_on_two_streams_bit_identical(network):
@@ -1377,7 +1409,7 @@ def _oracle_bs64():
     return _BS64['x'], _BS64['ref']
 
 
-@pytest.mark.parametrize('cdt', ['f32', 'f32x6', 'f32+winograd', 'f32+winograd4'])
+@pytest.mark.parametrize('cdt', ['f32', 'f32x6', 'f32+winograd', 'f32+winograd4', 'f32+winograd4+x6head'])
 def test_full_forward_bs64_vs_oracle(network, cdt):
     """BASELINE configs[1] at ITS OWN size: B = 64 @224, four streams on the liveness-packed
     arena, the tile instantiations the dispatcher picks at this M.  features / betas /
@@ -1387,7 +1419,9 @@ def test_full_forward_bs64_vs_oracle(network, cdt):
     network.backbone.multi_stream = True
     network.backbone.compute_dtype = cdt.split('+')[0]
     network.backbone.conv_algo = {'winograd': 'auto', 'winograd4': 'winograd4'}.get(
-        cdt.split('+')[-1], 'direct')
+        (cdt.split('+') + [''])[1], 'direct')
+    keep_x6 = network.backbone.x6_gemm_min_batch
+    network.backbone.x6_gemm_min_batch = 64 if cdt.endswith('x6head') else keep_x6      # (opt-in: head GEMMs on bf16x6)
     try:
         with torch.no_grad():
             out = network(x, None)
@@ -1395,6 +1429,7 @@ def test_full_forward_bs64_vs_oracle(network, cdt):
     finally:
         network.backbone.compute_dtype = 'f32'
         network.backbone.conv_algo = 'direct'
+        network.backbone.x6_gemm_min_batch = keep_x6
     st, rs = out['stage_02'], ref['stages'][-1]
     errs = {
         'features': np.abs(out['features'].cpu().numpy() - ref['features']).max(),

@@ -486,6 +486,43 @@ def test_split_k_policy_marks_the_7x7_branch_and_nothing_else(hrnet):
         _lib.tile_w4_ksplit(5)
 
 
+def test_head_gemms_can_take_the_bf16x6_arithmetic(hrnet):
+    """Opt-in (x6_gemm_min_batch > 0; off by default): compute_dtype 'f32', B >= x6_gemm_min_batch: the head's
+    fifteen wide 1x1 GEMMs (Cin, Cout >= 512) carry
+    SHAPY_TILE_X6 and their weights are the three bf16 planes [Cout][3][Kp]; no other layer does, no smaller batch
+    does; bench.py counts those layers with the matrix-pipe time they need."""
+    import types
+    from shapy_amd import _lib
+    sys.path.insert(0, ROOT)
+    import bench
+    keep = hrnet.conv_algo, hrnet.wino4_min_hw
+    try:
+        hrnet.conv_algo, hrnet.wino4_min_hw = 'winograd4', 7
+        P0 = hrnet._build_plan(224, 224)
+        hrnet._x6_eff = True
+        P1 = hrnet._build_plan(224, 224)
+    finally:
+        hrnet._x6_eff = False
+        hrnet.conv_algo, hrnet.wino4_min_hw = keep
+    assert not any(o['tile'] & _lib.TILE_X6 for o in P0.ops if o['type'] == _lib.OP_CONV)
+    x6 = [o for o in P1.ops if o['type'] == _lib.OP_CONV and o['tile'] & _lib.TILE_X6]
+    assert len(x6) == 15 and all(o['name'].startswith('conv_layers.') and o['ksize'] == 1 for o in x6)
+    assert sorted({(o['Cin'], o['Cout']) for o in x6}) == [(512, 2048), (1536, 512), (1536, 2048), (2048, 512),
+                                                           (2048, 2048)]
+    assert all(o.get('wino_off', -1) < 0 and o.get('scrb') is None for o in x6)
+    # planes: 6 bytes per weight instead of 4
+    grow = sum(o['Cin'] * o['Cout'] * 2 for o in x6)
+    assert 0 <= P1.wbytes - P0.wbytes - grow < 16 * len(x6)
+    net = types.SimpleNamespace(backbone=hrnet)
+    f0 = bench.executed_mfma_flop_per_image(net, 224, plan=P0)
+    f32_part, bf16_part = bench.executed_mfma_flop_per_image(net, 224, plan=P1, parts=True)
+    macs_x6 = sum(49 * o['Cin'] * o['Cout'] for o in x6)
+    assert bf16_part == 12 * macs_x6 and f32_part == f0 - 2 * macs_x6
+    f1 = bench.executed_mfma_flop_per_image(net, 224, plan=P1)
+    assert abs(f1 - (f32_part + 2 * macs_x6 * 6 * 157.3 / 2500.0)) < 1.0 and f1 < f0
+    assert hrnet.x6_gemm_min_batch == int(os.environ.get('SHAPY_X6_GEMM_MIN_BATCH', '0'))      # off by default
+
+
 def test_bench_flop_accounting_algorithmic_vs_executed(hrnet):
     """bench.py: `roofline.achieved` counts the direct-convolution FLOPs of SURVEY.md 8(d) whatever
     the algorithm; `executed_mfma` what the matrix cores run (F(2x2): 16 products per 2x2 tile,
