@@ -13,13 +13,18 @@ One "step" of the default workload = one full forward of the regressor on one ba
 already resident in HBM (BASELINE.json configs[1]: "HRNet-W48 + SMPL-X head, random-init
 weights, 224x224 bs=64 fp32 on 1xMI355X"); with N > 1 every rank runs its own shard (weak
 scaling: 64 images per GPU) and the predicted betas are all-gathered with RCCL once per step on
-a side stream (joined when the next step issues its gather, shapy_amd/parallel.py).
+a side stream (joined when the next step issues its gather, shapy_amd/parallel.py).  Consecutive steps are
+software-pipelined (--pipeline on, the default): every step hands the next batch to the network, whose stem +
+layer1 then run under this batch's head on one of the executor's side streams (bit-identical outputs;
+shapy_amd/models/backbone/prefetch.py); the timed region holds exactly `steps` whole forwards of work.
 
 Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
   roofline      the roofline of the dominant kernel family.  regressor: MFMA; `achieved` = the
                 FLOPs the matrix cores EXECUTE (Winograd layers: 36 products per 4x4 tile / 16 per
-                2x2 tile and channel pair) / time of the backbone call, measured with HIP events
-                on the launch stream inside the timed loop, peak 157.3 TFLOP/s (f32 MFMA, dense),
+                2x2 tile and channel pair) / time per forward -- HIP events around the backbone call on
+                the launch stream with --pipeline off, the whole step period with --pipeline on (the
+                events then bracket only a part of a forward; `roofline.duration` says which) --,
+                peak 157.3 TFLOP/s (f32 MFMA, dense),
                 so frac <= 1 by construction; the direct-convolution-equivalent rate (2 x
                 18,466,524,160 MAC per image) is `algorithmic_equiv_tflops`.
                 measurements / smplx / bvh: HBM, algorithmic bytes
@@ -32,7 +37,9 @@ Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
   rccl_ranks / per_rank   (N > 1) number of RCCL ranks and each rank's own images/s
   also          (default N = 1 run) compact sub-records of the OTHER BASELINE configurations, timed
                 after the headline's timed region: configs[0] (SMPL-X layer), configs[2]'s per-GPU
-                shard (bf16, bs 32), configs[3] (1,000 meshes), the LBVH path, the 256 x 256 crop
+                shard (bf16, bs 32), configs[3] (1,000 meshes), the LBVH path, the 256 x 256 crop, the
+                headline one forward at a time, the opt-in bf16x6 head GEMMs; the same values as flat
+                also_<key>_{value,ms,roofline_frac} scalars at the top level
 """
 import argparse
 import json
