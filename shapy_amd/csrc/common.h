@@ -38,6 +38,10 @@ inline int hip_rc(hipError_t e) { return (int)e; }
     if (_e != hipSuccess) return (int)_e;     \
   } while (0)
 
+// ReLU as compare + select: a NaN activation stays NaN, as torch.relu keeps it (a max with 0 would return 0 and
+// hide a numerical blow-up from the Winograd guard and from every check downstream).  Same bits for any other input.
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -131,7 +131,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK &p, f32x4 (&acc)[TM][T
         for (int r = 0; r < 4; ++r) {
           const int row = row0 + i * 16 + r;
           if (col < p.Cout && row < p.M) {
-            const float o = p.relu ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
+            const float o = p.relu ? relu_keep_nan(acc[i][j][r]) : acc[i][j][r];
             T::store(p.out, (long)row * p.out_ld + p.out_coff + col, o);
           }
         }
@@ -170,7 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK &p, f32x4 (&acc)[TM][T
             for (int q = 0; q < RG * UPS; ++q) {
               const float o = v + tmp[q];
               T::store(p.out, obase + ((long)(dy0 + q / UPS) * WoU + q % UPS) * p.out_ld,
-                       p.relu ? fmaxf(o, 0.f) : o);
+                       p.relu ? relu_keep_nan(o) : o);
             }
           }
         }
@@ -293,7 +293,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvK &p, f32x4 (&acc)[T
 #pragma unroll
           for (int e = 0; e < CG; ++e) {
             o[e] = v[e] + rv[dx][e];
-            if (p.relu) o[e] = fmaxf(o[e], 0.f);
+            if (p.relu) o[e] = relu_keep_nan(o[e]);
           }
           VecIO<T>::store(p.out, (pix0 + (long)dy * WoU + dx) * p.out_ld + p.out_coff + col, o);
         }
@@ -304,7 +304,7 @@ __device__ __forceinline__ void conv_epilogue_vec(const ConvK &p, f32x4 (&acc)[T
           for (int e = 0; e < CG && col + e < p.Cout; ++e) {
             const long pi = pix0 + (long)dy * WoU + dx;
             const float x = v[e] + (p.res ? T::load(p.res, pi * p.res_ld + p.res_coff + col + e) : 0.f);
-            T::store(p.out, pi * p.out_ld + p.out_coff + col + e, p.relu ? fmaxf(x, 0.f) : x);
+            T::store(p.out, pi * p.out_ld + p.out_coff + col + e, p.relu ? relu_keep_nan(x) : x);
           }
     }
   }

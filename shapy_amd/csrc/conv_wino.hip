@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, ((TM == 1 && NN <= 3) ? 3 : 2)) void conv_wino
           f32x4 v = y[a][bb] + rv[a][bb];
           if (p.relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = relu_keep_nan(v[e]);
           }
           *reinterpret_cast<f32x4 *>(out + pix[a][bb] * p.out_ld + p.out_coff + col) = v;
         }

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 4) void stem_conv_kernel(const float *__restri
     OutT *o = out + (pix0 + px) * out_ld + g * 8;
     float r[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = fmaxf(acc[px][i >> 1][i & 1] + bs[i], 0.f);
+    for (int i = 0; i < 8; ++i) r[i] = relu_keep_nan(acc[px][i >> 1][i & 1] + bs[i]);
     if (vec) {
       store_row8(o, r);
     } else {

@@ -444,6 +444,39 @@ def test_conv_winograd4_falls_back_to_direct_beyond_1gib(lib):
     assert (direct[:2].cpu().double() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize('kind', ['direct', 'direct_scalar', 'ups', 'winograd', 'winograd4', 'f32x6', 'bf16'])
+@pytest.mark.parametrize('relu', [True, False])
+def test_conv_kernels_keep_nan_through_relu(lib, kind, relu):
+    """torch.relu(NaN) is NaN.  A max with zero would turn a NaN activation into 0 and hide a numerical blow-up
+    from the Winograd guard and from every check downstream: every epilogue takes ReLU as compare +
+    select.  One NaN in the input: each output whose receptive field holds it is NaN in every channel; the
+    direct kernels leave everything else finite."""
+    Cin, Cout = (48, 48) if kind == 'winograd4' else (32, 70 if kind == 'direct_scalar' else 64)
+    ks = 1 if kind == 'ups' else 3
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 12, 12, Cin, generator=g)
+    x[1, 5, 6, 3] = float('nan')
+    w = torch.randn(Cout, ks, ks, Cin, generator=g) / np.sqrt(ks * ks * Cin)
+    b = torch.randn(Cout, generator=g)
+    x, w, b = x.cuda(), w.cuda(), b.cuda()
+    ups = 2 if kind == 'ups' else 1
+    res = torch.randn(2, 12 * ups, 12 * ups, Cout, generator=g).cuda()
+    if kind == 'bf16':
+        x, w, res = x.bfloat16(), w.bfloat16(), res.bfloat16()
+    out = _conv_call(lib, x, w, b, res, relu, 1, ks // 2, ups=ups, wino={'winograd': True, 'winograd4': 4}.get(kind, False),
+                     x6=kind == 'f32x6').float()
+    nan = torch.isnan(out)
+    r = ks // 2
+    field = torch.zeros_like(nan[..., 0])
+    field[1, (5 - r) * ups:(5 + r + 1) * ups, (6 - r) * ups:(6 + r + 1) * ups] = True
+    assert nan[field].all(), f'{int((~nan[field]).sum())} outputs lost the NaN'
+    assert not nan[0].any()                                  # the other image is untouched
+    if not kind.startswith('winograd'):                      # (a Winograd tile spreads it over its 2x2 / 4x4 outputs)
+        assert not nan[~field].any()
+    if relu:
+        assert (out[~nan] >= 0).all()
+
+
 X6_CASES = [c for c in CONV_CASES if c[10] in (0, 5, 8, 2, 6, 3, 7)] + [
     (2, 12, 12, 48, 48, 3, 1, 1, True, True, 8),      # Cin = 48: K chunks straddle taps
     (2, 9, 11, 20, 70, 3, 1, 1, False, False, 0),     # Cin % 32 != 0, Cin < 32, N tail
