@@ -317,7 +317,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self._n_forward = 0
         self._prefetch = ProloguePrefetch()
         #: forward(x, prefetch=next_x): batches up to this size issue the next prologue BEFORE their own launches
-        self.prefetch_before_max_batch = 8
+        self.prefetch_before_max_batch = 16
         self._capture_warned = False
         self.calibration_report = None
         self._calibrated_ver = None

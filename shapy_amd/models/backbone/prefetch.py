@@ -10,9 +10,10 @@ for its event and runs only the rest of the op list.  Anything else -- another t
 rebuilt plan -- is a full forward in the other workspace and the stale prologue is never looked at.
 
 Same kernels, same order per image: features are bit-identical with and without (tests/test_gpu_parity.py).
-Measured (profiles/r05o_prologue_prefetch_ab.txt, backbone only): float32 B = 64 12.45 -> 12.17 ms, bf16
-B = 32 3.72 -> 3.50 ms, float32 B = 8 3.86 -> 3.66 ms (issued BEFORE the rest there: a small batch leaves lane 3
-idle through stages 2-3; behind lane 3's own stage-4 work it would wait for the whole latency chain).
+Measured (profiles/r05o_prologue_prefetch_ab.txt, backbone only): float32 B = 64 12.45 -> 12.17 ms, B = 32 7.15 ->
+6.86, B = 16 4.96 -> 4.68, B = 8 3.86 -> 3.66; bf16 B = 32 3.72 -> 3.50, B = 64 6.11 -> 5.92.  Up to B = 16 the
+prologue is issued BEFORE the rest (a small batch leaves lane 3 idle through stages 2-3; behind lane 3's own
+stage-4 work it would wait for the whole latency chain: B = 8 4.18 ms), larger batches issue it behind the rest.
 """
 import ctypes
 

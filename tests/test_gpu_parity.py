@@ -875,7 +875,7 @@ def test_hrnet_event_driven_plan_equals_barrier_plan(network, B, size, graph):
 def test_hrnet_prefetched_prologue_bit_identical(network, B, size, cdt):
     """forward(x, prefetch=next_x): the next batch's stem + layer1 on a side stream in a second workspace
     (backbone/prefetch.py).  Same kernels in the same order per image -> the features of a pipelined loop over
-    alternating inputs equal the plain forwards bit for bit; B <= 8 issues the prologue before the rest, larger
+    alternating inputs equal the plain forwards bit for bit; B <= 16 issues the prologue before the rest, larger
     batches behind it.  A stash that does not match the next call (another tensor, an in-place edit) is ignored."""
     from shapy_amd.models.backbone import hrnet as hrnet_mod
     from shapy_amd.utils import synthetic as syn
