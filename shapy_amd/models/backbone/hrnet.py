@@ -316,7 +316,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.wino_guard_recheck_every = int(os.environ.get('SHAPY_WINO_GUARD_RECHECK', '0'))
         self._n_forward = 0
         self._prefetch = ProloguePrefetch()
-        #: forward(x, prefetch=next_x): batches up to this size issue the next prologue BEFORE their own launches
+        #: forward(x, prefetch=next_x): up to this size the prologue reaches to stage 2 and goes BEFORE the own launches
         self.prefetch_before_max_batch = 16
         self._capture_warned = False
         self.calibration_report = None
@@ -837,7 +837,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             blob = np.frombuffer(b''.join(P.wchunks), dtype=np.uint8)
             weights = torch.from_numpy(blob.copy()).to(device)
         eng = dict(ops=arr, n_ops=n, weights=weights, ws_per_img=ws_per_img, cnt_per_img=P.cnt_ints,
-                   plan=P, ws=None, graphs={}, cut=cut_of(P) if self._dag_eff else 0,
+                   plan=P, ws={}, graphs={}, cuts=(cut_of(P, 1), cut_of(P, 2)) if self._dag_eff else (0, 0),
                    feat_dim=P.ops[-1]['Cin'], esz=2 if bf16 else 4,
                    dtype={'f32': _lib.DTYPE_F32, 'bf16': _lib.DTYPE_BF16,
                           'f32x6': _lib.DTYPE_F32X6}[self.compute_dtype])
@@ -1022,33 +1022,32 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         need = eng['ws_per_img'] * B * eng['esz']
         # one workspace (+ split-K counters) per CALLER stream: forwards issued on different streams
         # (several batches in flight) must not share activations; a second one for `prefetch=` (prefetch.py)
-        if eng['ws'] is None:
-            eng['ws'] = {}
         sk = torch.cuda.current_stream().cuda_stream
         ent = eng['ws'].get(sk)
         if ent is None or ent['ws'][0].numel() < need or ent['B'] < B:
             ent = eng['ws'][sk] = dict(ws=[torch.empty(need, dtype=torch.uint8, device=x.device), None],
-                                       cnt=self._counters(eng, B, x.device), B=B, cur=0)
+                                       cnt=[self._counters(eng, B, x.device), None], B=B, cur=0)
         feat = torch.empty(B, eng['feat_dim'], dtype=torch.float32, device=x.device)
 
-        def run(first, n, inp, ws, multi, stream):
-            return lib.shapy_hrnet_run(ops_from(eng, first), n, _lib.ptr(eng['weights']), _lib.ptr(inp), _lib.ptr(ws),
-                                       eng['ws_per_img'], _lib.ptr(ent['cnt']), eng['cnt_per_img'], _lib.ptr(feat),
-                                       B, H, W, multi, eng['dtype'], stream)
+        def run(first, n, inp, a, multi, stream):        # ops [first, first + n) in workspace a (its own counters)
+            return lib.shapy_hrnet_run(ops_from(eng, first), n, _lib.ptr(eng['weights']), _lib.ptr(inp),
+                                       _lib.ptr(ent['ws'][a]), eng['ws_per_img'], _lib.ptr(ent['cnt'][a]),
+                                       eng['cnt_per_img'], _lib.ptr(feat), B, H, W, multi, eng['dtype'], stream)
         pf, first = self._prefetch.take(x, eng, ent, sk), 0
-        if pf is not None:                    # this batch's stem + layer1 ran under the previous batch
+        if pf is not None:                    # this batch's stem + layer1 (+ stage 2) ran under the previous batch
             torch.cuda.current_stream().wait_event(pf['done'])
-            ent['cur'], first = pf['arena'], eng['cut']
-        ahead = (prefetch is not None and eng['cut'] > 0 and self.multi_stream and self._prefetch.usable(prefetch, x)
+            ent['cur'], first = pf['arena'], pf['cut']
+        early = B <= self.prefetch_before_max_batch       # small batches: deeper cut, issued before the rest
+        cut = eng['cuts'][1 if early and eng['cuts'][1] else 0]
+        ahead = (prefetch is not None and cut > 0 and self.multi_stream and self._prefetch.usable(prefetch, x)
                  and not torch.cuda.is_current_stream_capturing())
         ev = self._prefetch.ready_event(ent) if ahead else None
         rc = 0
-        if ahead and B <= self.prefetch_before_max_batch:
-            rc = self._prefetch.issue(lib, run, eng, ent, prefetch, ev, sk, need)
-        rc = rc or run(first, eng['n_ops'] - first, x, ent['ws'][ent['cur']], int(self.multi_stream),
-                       _lib.current_stream())
-        if not rc and ahead and B > self.prefetch_before_max_batch:
-            rc = self._prefetch.issue(lib, run, eng, ent, prefetch, ev, sk, need)
+        if ahead and early:
+            rc = self._prefetch.issue(lib, run, eng, ent, prefetch, ev, sk, need, cut)
+        rc = rc or run(first, eng['n_ops'] - first, x, ent['cur'], int(self.multi_stream), _lib.current_stream())
+        if not rc and ahead and not early:
+            rc = self._prefetch.issue(lib, run, eng, ent, prefetch, ev, sk, need, cut)
         if rc != 0:
             del eng['ws'][sk]         # a failed forward may leave arrival counters behind: start clean
             self._prefetch.pending = None

@@ -14,6 +14,10 @@ Measured (profiles/r05o_prologue_prefetch_ab.txt, backbone only): float32 B = 64
 6.86, B = 16 4.96 -> 4.68, B = 8 3.86 -> 3.66; bf16 B = 32 3.72 -> 3.50, B = 64 6.11 -> 5.92.  Up to B = 16 the
 prologue is issued BEFORE the rest (a small batch leaves lane 3 idle through stages 2-3; behind lane 3's own
 stage-4 work it would wait for the whole latency chain: B = 8 4.18 ms), larger batches issue it behind the rest.
+Small batches are chains of latency-bound launches, and a second chain beside the first is nearly free: up to
+B = 16 the cut is the SECOND barrier (stem + layer1 + stage 2 as the prologue, 35 ops): B = 1 3.21 -> 2.80 ms,
+B = 8 3.83 -> 3.39, B = 16 5.00 -> 4.36; at B = 64 that cut loses (12.32 against 12.17), and everything in front of
+stage 4 (160 serial ops) loses at every size.
 """
 import ctypes
 
@@ -24,17 +28,17 @@ from ... import _lib
 LANE = 3                 # the 4th branch's stream: idle until stage 4
 
 
-def cut_of(plan):
-    """Index of the first op of the 'rest' (the plan's first barrier), or 0 when the ops in front of it cannot
-    run as a self-contained serial prologue: a split-K layer among them (its arrival counters belong to the
-    caller's stream), or a later op that waits for one of their events (the prologue records none)."""
+def cut_of(plan, nth=1):
+    """Index of the first op of the 'rest' -- the plan's nth barrier (1: transition1, the prologue is stem + layer1;
+    2: transition2, + stage 2) --, or 0 when the ops in front of it cannot run as a self-contained serial prologue:
+    a later op waits for one of their events (the prologue records none).  Split-K layers may be among them: every
+    workspace has arrival counters of its own."""
     ops = plan.ops
-    cut = next((i for i, o in enumerate(ops) if o['barrier_before']), 0)
-    if cut <= 0:
+    bars = [i for i, o in enumerate(ops) if o['barrier_before']]
+    if len(bars) < nth:
         return 0
+    cut = bars[nth - 1]
     sigs = {o['sig'] for o in ops[:cut] if o['sig'] >= 0}
-    if any(o.get('scrb') is not None or o.get('cnt_n', 0) for o in ops[:cut]):
-        return 0
     for o in ops[cut:]:                      # (event slots are reused: a slot signalled again belongs to the rest)
         if any(w in sigs for w in o['wait']):
             return 0
@@ -73,11 +77,15 @@ class ProloguePrefetch:
 
     def take(self, x, eng, ent, sk):
         """The stashed prologue of exactly this input, or None (the stash is dropped either way).  The stash holds
-        the tensor, the plan and the workspace entry themselves: none of their addresses can have been reused."""
+        the tensor, the plan and the workspace entry themselves: none of their addresses can have been reused.
+        A stash that does NOT match may still be running: the caller's stream waits for it before the forward that
+        follows may hand its workspace to the next prologue."""
         pf, self.pending = self.pending, None
         if pf is not None and pf['eng'] is eng and pf['ent'] is ent and pf['key'] == self.key(x, sk):
             self.used += 1
             return pf
+        if pf is not None and pf['sk'] == sk:
+            torch.cuda.current_stream().wait_event(pf['done'])
         return None
 
     @staticmethod
@@ -93,20 +101,25 @@ class ProloguePrefetch:
         ent['ev'].record()
         return ent['ev']
 
-    def issue(self, lib, run, eng, ent, nx, ev, sk, need):
+    def issue(self, lib, run, eng, ent, nx, ev, sk, need, cut):
         other = 1 - ent['cur']
         if ent['ws'][other] is None:
             ent['ws'][other] = torch.empty(max(need, ent['ws'][0].numel()), dtype=torch.uint8, device=nx.device)
+            c0 = ent['cnt'][0]                     # the second workspace has arrival counters of its own
+            ent['cnt'][other] = None if c0 is None else torch.zeros_like(c0)
             ent['done'] = [torch.cuda.Event(), torch.cuda.Event()]
         side = self.side_stream(lib, nx.device)
         side.wait_event(ev)
         # the side stream reads / writes these after the caller may have dropped them
         nx.record_stream(side)
         ent['ws'][other].record_stream(side)
-        rc = run(0, eng['cut'], nx, ent['ws'][other], 0, ctypes.c_void_p(side.cuda_stream))
+        if ent['cnt'][other] is not None:
+            ent['cnt'][other].record_stream(side)
+        rc = run(0, cut, nx, other, 0, ctypes.c_void_p(side.cuda_stream))
         if rc != 0:
             return rc
         ent['done'][other].record(side)
-        self.pending = dict(key=self.key(nx, sk), eng=eng, ent=ent, arena=other, done=ent['done'][other], x=nx)
+        self.pending = dict(key=self.key(nx, sk), eng=eng, ent=ent, sk=sk, arena=other, done=ent['done'][other], x=nx,
+                            cut=cut)
         self.issued += 1
         return 0

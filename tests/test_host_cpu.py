@@ -224,32 +224,34 @@ def test_prologue_cut_is_self_contained(hrnet, B):
     finally:
         hrnet._ksplit_eff = hrnet._direct_ksplit_eff = None
         hrnet._dag_eff, hrnet.conv_algo, hrnet.wino4_min_hw = keep
-    cut = cut_of(P)
-    assert cut == 15 and P.ops[cut]['name'] == 'transition1.0' and P.ops[cut]['barrier_before']
-    written = set()
-    for o in P.ops[:cut]:
-        for key in ('inb', 'resb'):
-            assert o.get(key) is None or id(o[key]) in written, o.get('name')
-        assert o.get('scrb') is None
-        written.add(id(o['outb']))
-    # what the rest reads of the prologue is its last output only
-    last = P.ops[cut - 1]['outb']
-    for o in P.ops[cut:]:
-        for key in ('inb', 'resb'):
-            assert o.get(key) is None or id(o[key]) not in written or o[key] is last
-    # a prologue with a split-K layer, or a rest that waits for a prologue event, has no cut
-    P.ops[3]['cnt_n'] = 8
-    assert cut_of(P) == 0
-    P.ops[3]['cnt_n'] = 0
+    assert cut_of(P, 1) == 15 and cut_of(P, 2) == 35 and cut_of(P, 99) == 0
+    for nth, cut, name in ((1, 15, 'transition1.0'), (2, 35, 'transition2.2.0')):
+        assert P.ops[cut]['name'] == name and P.ops[cut]['barrier_before']
+        written = set()
+        for o in P.ops[:cut]:
+            for key in ('inb', 'resb'):
+                assert o.get(key) is None or id(o[key]) in written, o.get('name')
+            written.add(id(o['outb']))
+            if o.get('scrb') is not None:
+                written.add(id(o['scrb']))
+        # what the rest reads of the prologue: the outputs of its last module only (layer1's output; the two
+        # branch outputs of stage 2's fuse layers)
+        live = {id(o[key]) for o in P.ops[cut:] for key in ('inb', 'resb') if o.get(key) is not None} & written
+        assert 1 <= len(live) <= 2 * nth
+    # the B <= 8 bucket splits the 96-channel F(4x4) layers of stage 2: split-K layers inside the deeper prologue
+    # (every workspace has arrival counters of its own)
+    assert any(o.get('scrb') is not None for o in P.ops[:35]) == (B <= 8)
+    cut = 15
+    # a rest that waits for a prologue event has no cut
     P.ops[cut + 1]['wait'] = [P.ops[1]['sig'], -1, -1]
-    assert P.ops[1]['sig'] >= 0 and cut_of(P) == 0
+    assert P.ops[1]['sig'] >= 0 and cut_of(P, 1) == 0
     # the stash: same memory + same version + same plan + same workspace entry + same stream, else nothing
     pf, eng, ent = ProloguePrefetch(), {}, {}
     x = torch.zeros(2, 3, 32, 32)
-    pf.pending = dict(key=pf.key(x, 7), eng=eng, ent=ent, arena=1, done=None, x=x)
+    pf.pending = dict(key=pf.key(x, 7), eng=eng, ent=ent, sk=7, arena=1, done=None, x=x, cut=15)
     assert pf.take(x[:], eng, ent, 7)['arena'] == 1 and pf.pending is None and pf.used == 1
     for other in (dict(x=x.clone()), dict(eng={}), dict(ent={}), dict(sk=8), dict(edit=True)):
-        pf.pending = dict(key=pf.key(x, 7), eng=eng, ent=ent, arena=1, done=None, x=x)
+        pf.pending = dict(key=pf.key(x, 7), eng=eng, ent=ent, sk=-1, arena=1, done=None, x=x, cut=15)
         if other.get('edit'):
             x.add_(1)
         assert pf.take(other.get('x', x), other.get('eng', eng), other.get('ent', ent), other.get('sk', 7)) is None
