@@ -73,6 +73,39 @@ def _reduce_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_evaluator_run_looks_one_batch_ahead():
+    """Evaluator.run uploads the NEXT batch before running the current one and hands it to networks that declare
+    `accepts_next_images` (SMPLXRegressor: its stem + layer1 then run under the current batch's head); every batch is
+    evaluated once, in order, the last one without a successor; other networks are called as the reference calls them."""
+    from shapy_amd.config.node import ConfigNode
+    from shapy_amd.evaluation import Evaluator
+    ev = Evaluator(ConfigNode({}))
+    ev.compute_metric = lambda stage_out, targets, metrics: {'v2v_t': stage_out['err']}
+    data = [(torch.full((2, 3, 4, 4), float(i)), {'id': i}) for i in range(4)]
+    calls = []
+
+    class Net(torch.nn.Module):
+        accepts_next_images = True
+
+        def forward(self, images, targets, device=None, next_images=None):
+            calls.append((float(images[0, 0, 0, 0]), targets['id'],
+                          None if next_images is None else float(next_images[0, 0, 0, 0])))
+            return {'num_stages': 1, 'stage_00': {'err': images[:, 0, 0, 0].double() / 1000.0}}
+
+    means = ev.run(Net(), iter(data), 'cpu', metric_names=())
+    assert calls == [(0.0, 0, 1.0), (1.0, 1, 2.0), (2.0, 2, 3.0), (3.0, 3, None)]
+    assert abs(means['v2v_t'] - 1.5) < 1e-12                  # mean of 0, 1, 2, 3 (x 1000: mm)
+
+    class Plain(torch.nn.Module):                              # no such attribute: the reference's call
+        def forward(self, images, targets, device=None):
+            calls.append(targets['id'])
+            return {'num_stages': 1, 'stage_00': {'err': images[:, 0, 0, 0].double()}}
+
+    del calls[:]
+    ev.run(Plain(), data[:1], 'cpu', metric_names=())
+    assert calls == [0] and ev.run(Plain(), [], 'cpu', metric_names=()) == {}
+
+
 def test_evaluator_reduce_gloo_world2():
     """The sharded accumulation equals the single-process mean (evaluation.py:753-757)."""
     import torch.multiprocessing as mp
