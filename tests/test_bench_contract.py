@@ -91,3 +91,41 @@ def test_round3_bvh_line():
     assert r['parity']['faces_equal'] and r['parity']['bcs_equal']
     rf = r['roofline']
     assert rf['bound'] == 'hbm' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+
+
+@pytest.mark.parametrize('name,pipelined,head', [
+    ('r05s_bench_default_with_also.json', True, 'f32 MFMA'),
+    ('r05p_bench_pipeline_off.json', False, 'f32 MFMA'),
+    ('r05v_bench_head_gemm_bf16x6.json', True, 'bf16x6')])
+def test_round5_bench_lines(name, pipelined, head):
+    """Round 5: the default line is the pipelined loop (every step hands the next batch to the network) and says so
+    -- `roofline` then divides by the whole step period, never by the events that bracket only a part of a forward;
+    `--pipeline off` keeps the events; the opt-in bf16x6 head counts its layers by matrix-pipe time, so `frac`
+    stays a fraction and DROPS although the value rises."""
+    with open(osp.join(ROOT, 'profiles', name)) as f:
+        r = json.loads(f.read().strip().splitlines()[-1])
+    with open(osp.join(ROOT, 'BASELINE.json')) as f:
+        assert r['metric'] == json.load(f)['metric']
+    assert r['dtype'] == 'f32' and r['n_gpus'] == 1 and r['config']['global_batch'] == 64
+    assert r['config']['pipelined_batches'] is pipelined
+    assert r['config'].get('head_gemm_arithmetic', 'f32 MFMA').startswith(head)    # (r05p predates the key)
+    rf = r['roofline']
+    assert rf['bound'] == 'mfma' and rf['peak'] == 157.3 and 0.0 < rf['frac'] <= 1.0
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    assert abs(rf['achieved'] - rf['flop_per_launch_group'] / rf['ms_per_launch_group'] / 1e9) < 1e-6 * rf['achieved']
+    if pipelined:
+        assert rf['duration'].startswith('step period') and abs(rf['ms_per_launch_group'] - r['ms_per_step']) < 0.05
+    else:
+        assert rf['duration'].startswith('HIP events') and rf['ms_per_launch_group'] < r['ms_per_step']
+    if head == 'bf16x6':
+        x6 = rf['bf16x6_layers']
+        want = x6['f32_core_flop_per_launch_group'] + x6['bf16_core_flop_per_launch_group'] * 157.3 / 2500.0
+        assert abs(want - rf['flop_per_launch_group']) < 1e-6 * want and rf['frac'] < 0.5
+    else:
+        assert rf.get('bf16x6_layers') is None and rf['frac'] > 0.5
+    if 'also' in r:                                   # the default run: flat copies of every sub-record
+        for tag, rec in r['also'].items():
+            assert 'error' not in rec, (tag, rec)
+            assert r[f'also_{tag}_value'] == rec['value'] and r[f'also_{tag}_roofline_frac'] == rec['roofline']['frac']
+        assert r['also_headline_one_forward_at_a_time_value'] < r['value'] < r['also_headline_with_head_gemms_on_bf16x6_value']
+        assert r['parity']['betas_l2'] < 1e-6 and r['cpu_baseline']['kind'] == 'port'
