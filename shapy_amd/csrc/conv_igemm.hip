@@ -487,6 +487,7 @@ int conv_prepare(const ShapyConv &d, ConvK &k, int *empty) {
   k.swz = (d.tile & 0x400) ? 0 : 1;
   k.no_nslab = (d.tile & 0x10000) ? 1 : 0;
   k.no_allk = (d.tile & 0x20000) ? 1 : 0;
+  k.w4_legacy = (d.tile & 0x1000000) ? 1 : 0;
   // F(4x4) split-K (conv_wino4.hip): SHAPY_TILE_W4_KSPLIT(S) in the tile word, slab + counters from
   // the caller
   k.ups_split = 1;

@@ -106,23 +106,18 @@ struct Wino4Split {
 
 // tile: the lane's tile (m_blk + l15); col4: its first output channel (n0 + 4 g4); g4 = lane >> 4.
 // S == 1: no split (sp / ticket unused).
-template <int S>
-__device__ __forceinline__ void wino4_epilogue(const Wino4Epi &e, const Wino4Split &sp, int ticket,
-                                               const f32x4 (&acc)[36], int tile, int col4, int g4,
-                                               int lane) {
+// xf(s): fills s[i][b] = (M A)[i][b], the accumulators transformed along x -- called exactly once on every
+// path (the four-wave kernel of conv_wino4q.hip completes rows 4 / 5 through an LDS exchange with a
+// workgroup barrier inside).
+template <int S, typename XF>
+__device__ __forceinline__ void wino4_epilogue_x(const Wino4Epi &e, const Wino4Split &sp, int ticket,
+                                                 XF &&xf, int tile, int col4, int g4, int lane) {
   constexpr int BAD = 0x40000000;
   const int H = e.H, W = e.W;
   const int TW = (W + 3) >> 2, TH = (H + 3) >> 2;
   const bool live = tile < e.tiles;
   f32x4 s[6][4];
-  auto transform_x = [&]() {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const f32x4 m[6] = {acc[6 * i + 0], acc[6 * i + 1], acc[6 * i + 2],
-                          acc[6 * i + 3], acc[6 * i + 4], acc[6 * i + 5]};
-      wino4_at4(m, s[i]);                                         // M A   (along x)
-    }
-  };
+  auto transform_x = [&]() { xf(s); };
   // slab addressing: per-lane part = the tile + channel quad, slice / unit / pixel = scalar offset
   const __amdgpu_buffer_rsrc_t rs_slab =
       __builtin_amdgcn_make_buffer_rsrc(S > 1 ? sp.slab : e.out, 0, S > 1 ? sp.slab_bytes : 0, 0x00020000);
@@ -274,6 +269,24 @@ __device__ __forceinline__ void wino4_epilogue(const Wino4Epi &e, const Wino4Spl
       __hip_atomic_store(sp.cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// a wave that holds all 36 positions of its (tile, channel) outputs (conv_wino4g.hip)
+template <int S>
+__device__ __forceinline__ void wino4_epilogue(const Wino4Epi &e, const Wino4Split &sp, int ticket,
+                                               const f32x4 (&acc)[36], int tile, int col4, int g4,
+                                               int lane) {
+  wino4_epilogue_x<S>(
+      e, sp, ticket,
+      [&](f32x4 (&s)[6][4]) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const f32x4 m[6] = {acc[6 * i + 0], acc[6 * i + 1], acc[6 * i + 2],
+                              acc[6 * i + 3], acc[6 * i + 4], acc[6 * i + 5]};
+          wino4_at4(m, s[i]);                                     // M A   (along x)
+        }
+      },
+      tile, col4, g4, lane);
 }
 
 }  // namespace shapy

@@ -312,6 +312,7 @@ int conv2d_wino4(ConvK k, hipStream_t s) {
   }
   // transformed filters larger than half an XCD's L2: one N slab per XCD (conv_tile_index)
   if (k.swz == 1 && k.nbx % 8 == 0 && k.wgt2_bytes > (2u << 20) && !k.no_nslab) k.swz = 2;
+  if (!n64 && !k.w4_legacy) return conv2d_wino4q_launch(k, S, s);     // four multiplying waves
   const dim3 grid(k.nbx * k.nby * S), blk(64 * (NW + 1));
   const int cps = chunks / S;                                    // chunks per slice
 #define W4_LAUNCH(KC, NWV, SV) hipLaunchKernelGGL((conv_wino4_kernel<KC, NWV, SV>), grid, blk, 0, s, k)
