@@ -178,8 +178,9 @@ __device__ __forceinline__ void wino4_epilogue_x(const Wino4Epi &e, const Wino4S
   };
   // reducer: column bb of the S - 1 OTHER slices' partials, in slice order (all loads unconditional:
   // a "register or load" choice per element would make hipcc branch around every load)
-  constexpr int SO = S > 1 ? S - 1 : 1;
-  f32x4 part[2][SO][4];
+  // (S > 2: one column of partials at a time -- two sets of S - 1 do not fit beside s[][] in 256 registers)
+  constexpr int SO = S > 1 ? S - 1 : 1, PB = S > 2 ? 1 : 2;
+  f32x4 part[PB][SO][4];
   auto pload = [&](int bb, f32x4 (&pv)[SO][4]) {
 #pragma unroll
     for (int k = 0; k < SO; ++k) {
@@ -206,7 +207,10 @@ __device__ __forceinline__ void wino4_epilogue_x(const Wino4Epi &e, const Wino4S
   for (int bb = 0; bb < 4; ++bb) {
     if (bb + 1 < 4) {
       rload(bb + 1, resv[(bb + 1) & 1]);
-      if constexpr (S > 1) pload(bb + 1, part[(bb + 1) & 1]);
+      if constexpr (S == 2) pload(bb + 1, part[(bb + 1) & 1]);
+    }
+    if constexpr (S > 2) {
+      if (bb > 0) pload(bb, part[0]);
     }
     const f32x4 colv[6] = {s[0][bb], s[1][bb], s[2][bb], s[3][bb], s[4][bb], s[5][bb]};
     f32x4 y[4];
@@ -222,8 +226,8 @@ __device__ __forceinline__ void wino4_epilogue_x(const Wino4Epi &e, const Wino4S
         f32x4 sum;
 #pragma unroll
         for (int j = 0; j < S; ++j) {
-          const f32x4 below = part[bb & 1][j < SO ? j : SO - 1][a];       // slice j when j < sp.slice
-          const f32x4 above = part[bb & 1][j > 0 ? j - 1 : 0][a];         // slice j when j > sp.slice
+          const f32x4 below = part[0][j < SO ? j : SO - 1][a];            // slice j when j < sp.slice
+          const f32x4 above = part[0][j > 0 ? j - 1 : 0][a];              // slice j when j > sp.slice
           const f32x4 t = j == sp.slice ? y[a] : (j < sp.slice ? below : above);
           sum = j == 0 ? t : sum + t;
         }

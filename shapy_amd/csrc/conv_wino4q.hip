@@ -16,10 +16,15 @@
 //         their own rows and finish as before (conv_wino4.h: bias, residual, ReLU, split-K, 16-byte stores).
 //       - staging: lane (tile, channel) of wave w loads the 6 x 6 patch of ONE channel for tiles 4 w .. + 3
 //         (36 buffer_load_dword, zero padding by the bounds check as in conv_wino4.hip), transforms it in
-//         scalar registers (B^T d B: 144 VALU) and writes 36 floats to the V image in LDS.  The work is cut
-//         into two-instruction steps that sit in the shadows of the chunk's MFMAs (one step per MFMA): rows
-//         first, then a column at a time -- a finished column's registers take the same column of the
-//         chunk after next.  No staging wave, no idle SIMD, 36 instead of 144 staging registers.
+//         registers and writes 36 floats to the V image in LDS.  On gfx950 an f32 MFMA and a VALU instruction
+//         of the same SIMD do not overlap (tools/mfma_fillers.hip: +6..13 cycles per v_fma between two
+//         v_mfma_f32_16x16x4_f32 of a wave, the same for a packed one; LDS / VMEM / SALU fillers are nearly
+//         free), so the transform is written for the fewest VALU instructions: the patch lives in row PAIRS
+//         (d[2k][j], d[2k+1][j]) -- the x pass is 36 v_pk_* on whole pairs, the y pass 8 per column with
+//         op_sel / neg_hi picking the halves -- 84 packed instructions instead of 144 scalar ones.  The work
+//         is cut into 60 micro-steps behind the chunk's last 60 MFMAs (SHAPY_W4Q_GROUP: one step per MFMA, or
+//         blocks of G steps behind every G-th): rows, then a column at a time; a finished column's registers
+//         take the same column of the chunk after next.  No staging wave, no idle SIMD, 36 staging registers.
 //   One barrier per chunk as before (V is double-buffered: chunk c + 1 is written while chunk c is read).
 //   Filter fragments come straight from L2 through a ring of 9 items (36 registers).
 #include <type_traits>
@@ -28,41 +33,109 @@
 #include "conv_wino4.h"
 
 // Timing builds only (SHAPY_HIPCC_FLAGS=-DSHAPY_W4Q_DBG=<mask>, results are WRONG): stages of the chunk loop
-// removed one at a time -- 1: transform VALU, 2: patch loads, 4: V writes, 8: filter refills, 16: V fragment reads.
+// removed one at a time -- 1: transform VALU (raw values are written), 2: patch loads, 4: V writes, 8: filter
+// refills, 16: V fragment reads.
 #ifndef SHAPY_W4Q_DBG
 #define SHAPY_W4Q_DBG 0
+#endif
+// arithmetic of the input transform: 2 = packed in both passes, 1 = packed x pass + scalar y pass, 0 = scalar
+// (a v_pk_* costs one issue slot like a scalar VALU instruction but twice its time on the FMA lanes the f32 MFMA
+// shares: tools/mfma_fillers.hip).  Same-box A/B at bs 64, images/s pipelined / one at a time
+// (profiles/r06f_w4q_transform_arithmetic_ab.txt): 3 + 1-wave kernel 5,190; packed both, spread 5,320 / 5,200;
+// scalar, spread 5,290 / 5,160; scalar, blocks of 12 5,365 / 5,230; packed x pass, blocks of 12 5,368 / 5,245.
+#ifndef SHAPY_W4Q_PK
+#define SHAPY_W4Q_PK 1
+#endif
+// staging steps per filler slot group (1: one step behind every MFMA; 3 / 6 / 12: blocks behind every 3rd / 6th / 12th)
+#ifndef SHAPY_W4Q_GROUP
+#define SHAPY_W4Q_GROUP 12
 #endif
 
 namespace shapy {
 
 namespace {
 
-// B^T (6 x 6) on a 6-vector in six steps of two independent VALU instructions, outputs over the inputs.
-// Order chosen for the shortest live ranges: c, e first (kept to the end), o0 / o5 (replace d0 / d5, which
-// nothing else reads), then a, b -- the last readers of d1..d4 -- and the four middle outputs.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// Packed float32 math spelled out: hipcc (ROCm 7.2) scalarises <2 x float> arithmetic on gfx950, and here the
+// instruction COUNT is the cost (header).  x * K + y with K an inline constant; k5 = (-5, -5) lives in a
+// register pair (5.0 is no inline constant and VOP3P takes no literal).
+#define W4Q_PKFMA_CONST(NAME, KSTR, KVAL)                                                             \
+  __device__ __forceinline__ f32x2 NAME(f32x2 x, f32x2 y) {                                            \
+    if constexpr (SHAPY_W4Q_PK == 0) return f32x2{fmaf(KVAL, x[0], y[0]), fmaf(KVAL, x[1], y[1])};     \
+    f32x2 o;                                                                                           \
+    asm("v_pk_fma_f32 %0, %1, " KSTR ", %2 op_sel_hi:[1,0,1]" : "=v"(o) : "v"(x), "v"(y));             \
+    return o;                                                                                          \
+  }
+W4Q_PKFMA_CONST(pkfma_p4, "4.0", 4.f)
+W4Q_PKFMA_CONST(pkfma_m4, "-4.0", -4.f)
+W4Q_PKFMA_CONST(pkfma_p2, "2.0", 2.f)
+W4Q_PKFMA_CONST(pkfma_m2, "-2.0", -2.f)
+#undef W4Q_PKFMA_CONST
+__device__ __forceinline__ f32x2 pkfma_v(f32x2 k, f32x2 x, f32x2 y) {
+  if constexpr (SHAPY_W4Q_PK == 0) return f32x2{fmaf(-5.f, x[0], y[0]), fmaf(-5.f, x[1], y[1])};
+  f32x2 o;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o) : "v"(k), "v"(x), "v"(y));
+  return o;
+}
+__device__ __forceinline__ f32x2 pkadd(f32x2 x, f32x2 y) {
+  if constexpr (SHAPY_W4Q_PK == 0) return f32x2{x[0] + y[0], x[1] + y[1]};
+  f32x2 o;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(o) : "v"(x), "v"(y));
+  return o;
+}
+__device__ __forceinline__ f32x2 pksub(f32x2 x, f32x2 y) {
+  if constexpr (SHAPY_W4Q_PK == 0) return f32x2{x[0] - y[0], x[1] - y[1]};
+  f32x2 o;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(x), "v"(y));
+  return o;
+}
+
+// B^T (6 x 6) along x on a 6-vector of ROW PAIRS (both rows get the same combination: plain packed math),
+// in place, six steps of two v_pk_* each.  Order chosen for the shortest live ranges: c, e first (kept to
+// the end), o0 / o5 (replace d0 / d5, which nothing else reads), then a, b -- the last readers of d1..d4 --
+// and the four middle outputs.
 struct BtTemps {
-  float a, b, c, e;
+  f32x2 a, b, c, e;
+  f32x2 k5;                    // (-5, -5)
 };
 template <int STEP>
-__device__ __forceinline__ void wino4_bt_step(float &d0, float &d1, float &d2, float &d3, float &d4,
-                                              float &d5, BtTemps &t) {
+__device__ __forceinline__ void wino4_bt_rows_step(f32x2 &d0, f32x2 &d1, f32x2 &d2, f32x2 &d3, f32x2 &d4,
+                                                   f32x2 &d5, BtTemps &t) {
   if constexpr (STEP == 0) {
-    t.c = d4 - d2;
-    t.e = d3 - d1;
+    t.c = pksub(d4, d2);
+    t.e = pksub(d3, d1);
   } else if constexpr (STEP == 1) {
-    d0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    d0 = pkfma_p4(d0, pkfma_v(t.k5, d2, d4));
   } else if constexpr (STEP == 2) {
-    d5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+    d5 = pkfma_p4(d1, pkfma_v(t.k5, d3, d5));
   } else if constexpr (STEP == 3) {
-    t.a = fmaf(-4.f, d2, d4);
-    t.b = fmaf(-4.f, d1, d3);
+    t.a = pkfma_m4(d2, d4);
+    t.b = pkfma_m4(d1, d3);
   } else if constexpr (STEP == 4) {
-    d1 = t.a + t.b;
-    d2 = t.a - t.b;
+    d1 = pkadd(t.a, t.b);
+    d2 = pksub(t.a, t.b);
   } else {
-    d3 = fmaf(2.f, t.e, t.c);
-    d4 = fmaf(-2.f, t.e, t.c);
+    d3 = pkfma_p2(t.e, t.c);
+    d4 = pkfma_m2(t.e, t.c);
   }
+}
+
+// B^T along y on one column held as three pairs P0 = (d0, d1), P1 = (d2, d3), P2 = (d4, d5); four steps of two
+// v_pk_* each; the outputs come back as pairs (o0, o5), (o1, o2), (o3, o4):
+//   (o0, o5) = 4 P0 - 5 P1 + P2
+//   U = P2 - 4 P1 -> a = U.lo      W = P1 - 4 P0 -> b = W.hi      C = P2 - P1 -> c = C.lo      E = P1 - P0 -> e = E.hi
+//   (o1, o2) = (a + b, a - b):   v_pk_add_f32 U, W   with op_sel (lo, hi) for both result halves, neg_hi on W
+//   (o3, o4) = (c + 2 e, c - 2 e):   v_pk_fma_f32 E, 2.0, C   with E.hi (negated for the high half), C.lo
+__device__ __forceinline__ f32x2 wino4_pk_sum_diff(f32x2 u, f32x2 w) {
+  f32x2 o;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(u), "v"(w));
+  return o;
+}
+__device__ __forceinline__ f32x2 wino4_pk_c_pm_2e(f32x2 e, f32x2 c) {
+  f32x2 o;
+  asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_hi:[1,0,0]" : "=v"(o) : "v"(e), "v"(c));
+  return o;
 }
 
 template <int I>
@@ -130,17 +203,90 @@ __global__ __launch_bounds__(256, 2) void conv_wino4q_kernel(ConvK p) {
   // (r ^ r >> 1) & 3 (conv_wino4.hip's layout: conflict-free ds_read_b128 fragments); a wave's
   // ds_write_b32 covers 4 rows x 64 bytes = every bank once
   const int st_off = tile_s * 64 + ((((ch >> 2) ^ tile_s ^ (tile_s >> 1)) & 3) << 4) + (ch & 3) * 4;
-  float raw[6][6];
+  f32x2 rp[3][6];                              // the patch in row pairs: rp[k][j] = (d[2k][j], d[2k+1][j])
   unsigned co_cur = 0;                         // column part of the load offsets, opaque to the compiler:
   auto set_col = [&](int j) {                  // otherwise hipcc hoists all 36 row + column sums out of the
     co_cur = col_off[j];                       // K loop and keeps them in registers
     asm volatile("" : "+v"(co_cur));
   };
   auto gload = [&](int i, int j, int chunk) {  // patch element (i, j) of chunk `chunk` of the slice
-    raw[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+    rp[i >> 1][j][i & 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
         rs_in, (int)(row_off[i] + co_cur), (cbase + chunk) * 64, 0));
   };
   BtTemps bt;
+  bt.k5 = f32x2{-5.f, -5.f};
+  asm volatile("" : "+v"(bt.k5));              // (kept in its two registers: not rematerialised per use)
+  // ---- staging micro-step m = 0 .. 59: the patch in `rp` -> V image at Vw; chunk `nxt` -> `rp` (if >= 0) ----
+  //   0..17   x pass of row pair m / 6, step m % 6
+  //   18..21  y pass of column 0;  then for j = 1..5 seven steps: y pass of column j interleaved with the
+  //           three load steps of column j - 1 (its registers are free);  57..59 loads of column 5
+  auto stage_micro = [&](auto mtag, char *Vw, int nxt) {
+    constexpr int m = decltype(mtag)::value;
+    auto ypass = [&](auto jtag, auto sttag) {
+      constexpr int j = decltype(jtag)::value, st = decltype(sttag)::value;
+      auto stv = [&](int i, float v) {
+        if constexpr (!(SHAPY_W4Q_DBG & 4)) *reinterpret_cast<float *>(Vw + (6 * i + j) * PSTR) = v;
+      };
+      if constexpr (SHAPY_W4Q_DBG & 1) {
+        if constexpr (st == 0) { stv(0, rp[0][j][0]); stv(5, rp[2][j][1]); }
+        if constexpr (st == 3) { stv(1, rp[0][j][1]); stv(2, rp[1][j][0]); stv(3, rp[1][j][1]); stv(4, rp[2][j][0]); }
+      } else if constexpr (SHAPY_W4Q_PK < 2 && KC > 0) {     // (generic loop: packed, the scalar form spills there)
+        // scalar y pass: d0..d5 = the halves of the column's three pairs
+        const float d0 = rp[0][j][0], d1 = rp[0][j][1], d2 = rp[1][j][0], d3 = rp[1][j][1], d4 = rp[2][j][0],
+                    d5 = rp[2][j][1];
+        if constexpr (st == 0) {
+          bt.c[0] = d4 - d2;
+          bt.e[0] = d3 - d1;
+          stv(0, fmaf(4.f, d0, fmaf(-5.f, d2, d4)));
+        } else if constexpr (st == 1) {
+          stv(5, fmaf(4.f, d1, fmaf(-5.f, d3, d5)));
+          bt.a[0] = fmaf(-4.f, d2, d4);
+        } else if constexpr (st == 2) {
+          bt.b[0] = fmaf(-4.f, d1, d3);
+          stv(3, fmaf(2.f, bt.e[0], bt.c[0]));
+          stv(4, fmaf(-2.f, bt.e[0], bt.c[0]));
+        } else {
+          stv(1, bt.a[0] + bt.b[0]);
+          stv(2, bt.a[0] - bt.b[0]);
+        }
+      } else if constexpr (st == 0) {
+        const f32x2 o = pkfma_p4(rp[0][j], pkfma_v(bt.k5, rp[1][j], rp[2][j]));
+        stv(0, o[0]); stv(5, o[1]);
+      } else if constexpr (st == 1) {
+        bt.a = pkfma_m4(rp[1][j], rp[2][j]);
+        bt.b = pkfma_m4(rp[0][j], rp[1][j]);
+      } else if constexpr (st == 2) {
+        bt.c = pksub(rp[2][j], rp[1][j]);
+        bt.e = pksub(rp[1][j], rp[0][j]);
+      } else {
+        const f32x2 o12 = wino4_pk_sum_diff(bt.a, bt.b), o34 = wino4_pk_c_pm_2e(bt.e, bt.c);
+        stv(1, o12[0]); stv(2, o12[1]); stv(3, o34[0]); stv(4, o34[1]);
+      }
+    };
+    auto loads = [&](auto jtag, auto sttag) {
+      constexpr int j = decltype(jtag)::value, st = decltype(sttag)::value;
+      if constexpr (!(SHAPY_W4Q_DBG & 2)) {
+        if (nxt >= 0) {
+          if constexpr (st == 0) set_col(j);
+          gload(2 * st, j, nxt);
+          gload(2 * st + 1, j, nxt);
+        }
+      }
+    };
+    if constexpr (m < 18) {
+      if constexpr (!(SHAPY_W4Q_DBG & 1))
+        wino4_bt_rows_step<m % 6>(rp[m / 6][0], rp[m / 6][1], rp[m / 6][2], rp[m / 6][3], rp[m / 6][4],
+                                  rp[m / 6][5], bt);
+    } else if constexpr (m < 22) {
+      ypass(ic<0>{}, ic<m - 18>{});
+    } else if constexpr (m < 57) {
+      constexpr int j = 1 + (m - 22) / 7, r = (m - 22) % 7;
+      if constexpr (r % 2 == 0) ypass(ic<j>{}, ic<r / 2>{});
+      else loads(ic<j - 1>{}, ic<r / 2>{});
+    } else {
+      loads(ic<5>{}, ic<m - 57>{});
+    }
+  };
 
   // ---------------- multiplying role ----------------
   const __amdgpu_buffer_rsrc_t rs_u =
@@ -175,26 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4q_kernel(ConvK p) {
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) bload(q, q, 0, true);
-    static_for<6>([&](auto i) {
-      static_for<6>([&](auto st) {
-        wino4_bt_step<st.value>(raw[i.value][0], raw[i.value][1], raw[i.value][2], raw[i.value][3],
-                                raw[i.value][4], raw[i.value][5], bt);
-      });
-    });
-    static_for<6>([&](auto j) {
-      static_for<6>([&](auto st) {
-        wino4_bt_step<st.value>(raw[0][j.value], raw[1][j.value], raw[2][j.value], raw[3][j.value],
-                                raw[4][j.value], raw[5][j.value], bt);
-      });
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-        *reinterpret_cast<float *>(lds + st_off + (6 * i + j.value) * PSTR) = raw[i][j.value];
-      if (CC > 1) {
-        set_col(j.value);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) gload(i, j.value, 1);
-      }
-    });
+    static_for<60>([&](auto m) { stage_micro(m, lds + st_off, CC > 1 ? 1 : -1); });
 
     Wino4Split sp;
     sp.slab = p.split_ws; sp.slab_bytes = p.split_bytes; sp.slice = slice;
@@ -240,30 +367,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino4q_kernel(ConvK p) {
             else bload(q % R, q + R - 27, cc + 1, more);
           }
           // (c) one staging step: chunk cc + 1 (in `raw`) -> LDS; chunk cc + 2 -> `raw`
+          // (c) staging micro-steps: one behind each of the chunk's last 60 MFMAs, or SHAPY_W4Q_GROUP of them
+          // together behind every SHAPY_W4Q_GROUP-th MFMA
           if (more) {
-            if constexpr (L >= 30 && L < 66 && !(SHAPY_W4Q_DBG & 1)) {                 // rows: T = d B (along x)
-              constexpr int i = (L - 30) / 6, st = (L - 30) % 6;
-              wino4_bt_step<st>(raw[i][0], raw[i][1], raw[i][2], raw[i][3], raw[i][4], raw[i][5], bt);
-            }
-            if constexpr (L >= 66 && L < 102) {                // columns: V = B^T T (along y), to LDS
-              constexpr int j = (L - 66) / 6, st = (L - 66) % 6;
-              if constexpr (!(SHAPY_W4Q_DBG & 1))
-                wino4_bt_step<st>(raw[0][j], raw[1][j], raw[2][j], raw[3][j], raw[4][j], raw[5][j], bt);
-              auto stv = [&](int i) {
-                if constexpr (!(SHAPY_W4Q_DBG & 4)) *reinterpret_cast<float *>(Vw + (6 * i + j) * PSTR) = raw[i][j];
-              };
-              if constexpr (st == 1) stv(0);
-              if constexpr (st == 2) stv(5);
-              if constexpr (st == 4) { stv(1); stv(2); }
-              if constexpr (st == 5) { stv(3); stv(4); }
-            }
-            if constexpr (L >= 72 && !(SHAPY_W4Q_DBG & 2)) {   // the finished column's next-but-one patch
-              constexpr int j = (L - 72) / 6, i = (L - 72) % 6;
-              if (more2) {
-                if constexpr (i == 0) set_col(j);
-                gload(i, j, cc + 2);
-              }
-            }
+            if constexpr ((L + 1) % SHAPY_W4Q_GROUP == 0)
+              static_for<SHAPY_W4Q_GROUP>([&](auto k) {
+                constexpr int m = L + 1 - SHAPY_W4Q_GROUP + k.value - 48;
+                if constexpr (m >= 0) stage_micro(ic<m>{}, Vw, more2 ? cc + 2 : -1);
+              });
           }
           __builtin_amdgcn_sched_barrier(0);
         });
@@ -313,17 +424,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino4q_kernel(ConvK p) {
               wino4_at4(m, s[i]);
             }
             const f32x4 s12 = acc[25] + acc[26], d12 = acc[25] - acc[26];
-            const f32x4 p0 = acc[24] + s12;
+            s[4][0] = acc[24] + s12;
+            s[4][1] = d12;
+            s[4][2] = s12;
+            s[4][3] = d12;
             wino4_lds_barrier();                 // wave 3's part is in LDS
-            f32x4 r[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) r[k] = *reinterpret_cast<const f32x4 *>(X + (wave * 8 + k) * PSTR);
-            s[4][0] = p0 + r[0];
-            s[4][1] = d12 + r[1];
-            s[4][2] = s12 + r[2];
-            s[4][3] = d12 + r[3];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s[5][k] = r[4 + k];
+            for (int k = 0; k < 4; ++k) {
+              s[4][k] = s[4][k] + *reinterpret_cast<const f32x4 *>(X + (wave * 8 + k) * PSTR);
+              s[5][k] = *reinterpret_cast<const f32x4 *>(X + (wave * 8 + 4 + k) * PSTR);
+            }
           },
           m_blk + l15, n_blk + 16 * wave + 4 * g, g, lane);
     }

@@ -261,6 +261,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: instead of F(2x2).  Empty by default: on layer1's 64 -> 64 it is 15 % faster in isolation
         #: (88 vs 104 us) but the forward does not move (profiles/r04t_*); on the head's 512 -> 512
         #: @7x7 it loses without a K split (131 vs 100 us).  (SHAPY_WINO4_N64="64,512" for A/B runs.)
+        #: A/B knob: input-channel classes that stay on the 3 + 1-wave F(4x4) kernel (SHAPY_W4_LEGACY="192,384")
+        self.wino4_legacy_cin = tuple(int(c) for c in os.environ.get('SHAPY_W4_LEGACY', '').split(',') if c)
         self.wino4_n64 = tuple(int(c) for c in os.environ.get('SHAPY_WINO4_N64', '').split(',') if c)
         #: F(4x4) split-K: {(Cin, most 4x4 tiles per image): S} -- a layer with that many input channels
         #: on a map of at most that many tiles runs S workgroups per output tile, each over Cin / S
@@ -549,7 +551,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 wino_off = P.add_weights(self._xform(name, 2, w))
             elif not (bf16 or x6) and self._use_wino4(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
                 wino_off = P.add_weights(self._xform(name, 4, w))
-                wino_flag = _lib.TILE_WINO4
+                wino_flag = _lib.TILE_WINO4 | (0x1000000 if cin_p in self.wino4_legacy_cin else 0)
                 # split-K (never inside a persistent grouped launch, which has no such form)
                 sl = 1 if group_member else self._ksplit(cin_p, Hi, Wi)
                 if sl > 1:
