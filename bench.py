@@ -695,10 +695,10 @@ def run_regressor(args, rank, world, local_rank):
     x = torch.from_numpy(x_np).to(dev)
     force_gather = bool(getattr(args, 'force_gather', False)) and world == 1 and not stub
     gather_mode = getattr(args, 'gather_mode', None)
-    if force_gather and gather_mode in ('work', 'side'):
-        # one-GPU rehearsal of the c10d variants of the N-rank step: a world-size-1 RCCL process group,
+    if force_gather and gather_mode == 'work':
+        # one-GPU rehearsal of the c10d fallback of the N-rank step: a world-size-1 RCCL process group,
         # so the collective, c10d's RCCL stream and the deferred join all exist in THIS process
-        # (the default mode 'rccl' needs no process group for one rank: shapy_amd/rccl.py)
+        # (the default mode 'lane' needs no process group for one rank: shapy_amd/rccl.py)
         import socket
         with socket.socket() as sk:
             sk.bind(('127.0.0.1', 0))
@@ -764,10 +764,26 @@ def run_regressor(args, rank, world, local_rank):
         per_rank = [float(t.item()) for t in allr]
     assert betas.shape == (world * B, 10)
     betas_all = betas.clone()
+    # after the clock: how long does the lane-1 gather keep the NEXT step's join waiting?  Three extra steps, each
+    # joined from the host right after the following step has been enqueued (BetasGatherer.wait(measure=True)); at
+    # N > 1 a slow rank would show up here as a lane-1 stall -- 0 when the gather finished long before.
+    join_wait_ms = None
+    if (world > 1 or force_gather) and not stub and gatherer.mode == 'lane':
+        waits = []
+        for _ in range(3):
+            gatherer.wait()
+            with torch.no_grad():
+                o2 = net(x, None)
+                gatherer(o2['stage_02']['betas'])
+                net.backbone(x)                      # the next step's backbone is in the queues ...
+            gatherer.wait(measure=True)              # ... when the host asks for the gather
+            waits.append(gatherer.last_join_wait_ms)
+        device_sync()
+        join_wait_ms = float(max(waits))
     gatherer.close()                   # (the communicator goes before the process group does)
     betas = betas_all
     if force_gather:
-        assert torch.equal(betas, out['stage_02']['betas']) and gatherer.issued == args.steps + args.warmup
+        assert torch.equal(betas, out['stage_02']['betas']) and gatherer.issued >= args.steps + args.warmup
         if dist.is_initialized():
             dist.destroy_process_group()
     assert torch.equal(betas_host, out['stage_02']['betas'].cpu())      # the D2H copy landed
@@ -903,13 +919,15 @@ def run_regressor(args, rank, world, local_rank):
         res['rccl_ranks'] = world
         res['per_rank'] = {'images_per_sec': per_rank,
                            'allgather': {'issued': gatherer.issued, 'mode': gatherer.mode,
-                                         'joined_by_next_step': gatherer.deferred_waits}}
+                                         'joined_by_next_step': gatherer.deferred_waits,
+                                         'lane_join_wait_ms_max_after_clock': join_wait_ms}}
     if force_gather:
         res['rccl_ranks'] = 1
         res['force_gather'] = {'mode': gatherer.mode, 'issued': gatherer.issued,
                                'joined_by_next_step': gatherer.deferred_waits,
+                               'lane_join_wait_ms_max_after_clock': join_wait_ms,
                                'note': 'world-size-1 RCCL communicator: the all_gather of the N-rank step on '
-                                       'ONE GPU (work / side: through c10d, with its RCCL stream)'}
+                                       'ONE GPU (work: through c10d, with its RCCL stream)'}
     import hashlib
     res['betas_sha1'] = hashlib.sha1(betas_host.numpy().tobytes()).hexdigest()[:16]
     if world == 1 and not getattr(args, 'no_also', False) and not getattr(args, '_sub', False):
@@ -970,7 +988,7 @@ def main():
                     help='N = 1 only: create a world-size-1 RCCL group and take BetasGatherer\'s '
                          'collective path (rehearsal of the N-rank step on one GPU; the line says '
                          '"rccl_ranks": 1)')
-    ap.add_argument('--gather-mode', default=None, choices=['lane', 'rccl', 'work', 'side'],
+    ap.add_argument('--gather-mode', default=None, choices=['lane', 'work'],
                     help='BetasGatherer issue mode (shapy_amd/parallel.py; default: lane = ncclAllGather '
                          'called directly on the executor\'s lane-1 stream, joined one step later)')
     ap.add_argument('--control-backend', default='gloo', choices=['gloo', 'nccl'],

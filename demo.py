@@ -88,21 +88,37 @@ def main(exp_cfg, demo_output_folder='demo_output', focal_length=5000, sensor_wi
     dataset = OpenPose(split=split, **part_cfg.get('openpose', {}))
     logger.info('%d people in %s', len(dataset), dataset.img_folder)
 
+    def prepared():
+        for batch in batches(dataset, exp_cfg.datasets.batch_size, rank, world):
+            imgs = [b[0] for b in batch]
+            targets = [b[1] for b in batch]
+            body_imgs = crop_and_normalize(imgs, [t.get_field('center') for t in targets],
+                                           [t.get_field('scale') for t in targets], crop_size, mean,
+                                           std, device=device)
+            yield imgs, targets, body_imgs
+
+    # one batch ahead (not in the reference loop, demo.py:307-353): the next batch's crops exist before this
+    # batch's forward is issued, and the network runs their stem + layer1 under this batch's head
+    # (SMPLXRegressor.forward(next_images=), models/backbone/prefetch.py; same outputs)
+    look_ahead = getattr(model, 'accepts_next_images', False)
     total_time, cnt = 0.0, 0
-    for batch in batches(dataset, exp_cfg.datasets.batch_size, rank, world):
-        imgs = [b[0] for b in batch]
-        targets = [b[1] for b in batch]
-        body_imgs = crop_and_normalize(imgs, [t.get_field('center') for t in targets],
-                                       [t.get_field('scale') for t in targets], crop_size, mean,
-                                       std, device=device)
+    it = prepared()
+    cur = next(it, None)
+    while cur is not None:
+        imgs, targets, body_imgs = cur
+        nxt = next(it, None)
         torch.cuda.synchronize()
         start = time.perf_counter()
-        out = model(body_imgs, targets)
+        if look_ahead and nxt is not None and nxt[2].shape == body_imgs.shape:
+            out = model(body_imgs, targets, next_images=nxt[2])
+        else:
+            out = model(body_imgs, targets)
         torch.cuda.synchronize()
         if getattr(model, 'compute_measurements', False):
             model.body_measurements.check_overflow()
         total_time += time.perf_counter() - start
         cnt += 1
+        cur = nxt
 
         cam = out['camera_parameters']
         hd_params = weak_persp_to_blender(

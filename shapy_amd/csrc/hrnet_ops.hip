@@ -2,6 +2,8 @@
 // Reference: regressor/human_shape/models/backbone/hrnet.py:426-498.
 #include <mutex>
 
+#include <stdio.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace shapy {
@@ -179,7 +181,14 @@ static int lane_stream(Lanes *L, int li, hipStream_t *out) {
   if (!L->s[li]) {
     int plo = 0, phi = 0;
     SHAPY_HIP_TRY(hipDeviceGetStreamPriorityRange(&plo, &phi));    // phi = highest (numerically lowest)
-    int pr = plo - (li % 3 + 1);
+    int up = li % 3 + 1;
+    if (const char *e = getenv("SHAPY_LANE_PRIO")) {               // A/B knob: "a,b,c" = steps above the lowest
+      int v[3] = {1, 2, 3};                                        // priority for lanes 1, 2, 3
+      if (sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3) up = v[li % 3];
+      static bool said = false;
+      if (!said) { said = true; fprintf(stderr, "shapy: stream priority range lowest %d .. highest %d\n", plo, phi); }
+    }
+    int pr = plo - up;
     if (pr < phi) pr = phi;
     SHAPY_HIP_TRY(hipStreamCreateWithPriority(&L->s[li], hipStreamNonBlocking, pr));
   }

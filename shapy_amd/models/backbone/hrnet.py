@@ -982,9 +982,18 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             g = eng['graphs'][key] = _CapturedForward(lib, eng, B, H, W, x.device, self.multi_stream)
         return g(x)
 
+    def drop_prefetch(self):
+        """Forget a prologue stashed by ``forward(..., prefetch=t)``.  RULE for ``t``: from that call until
+        ``forward(t)`` has been issued the tensor may only be written THROUGH TORCH (any in-place torch op bumps its
+        version counter and the stale prologue is ignored); whoever writes it another way -- a raw-pointer kernel,
+        a DLPack / ``__cuda_array_interface__`` alias, a peer copy -- calls this first (or simply does not pass
+        ``prefetch``).  tests/test_gpu_parity.py::test_hrnet_prefetch_stash_rules."""
+        self._prefetch.drop()
+
     def forward(self, x, prefetch=None):
         """``prefetch``: the NEXT batch (same shape, float32, contiguous, ready on the current stream): its stem + layer1
-        run under this batch's head and the next ``forward(that tensor)`` skips them (prefetch.py; bit-identical)."""
+        run under this batch's head and the next ``forward(that tensor)`` skips them (prefetch.py; bit-identical).
+        The tensor must not change behind torch's back in between: ``drop_prefetch``."""
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f'expected [B,3,H,W], got {tuple(x.shape)}')
         if self.training:
@@ -1043,6 +1052,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         cut = eng['cuts'][1 if early and eng['cuts'][1] else 0]
         ahead = (prefetch is not None and cut > 0 and self.multi_stream and self._prefetch.usable(prefetch, x)
                  and not torch.cuda.is_current_stream_capturing())
+        if ahead:
+            self._prefetch.second_workspace(ent, need, x.device)
         ev = self._prefetch.ready_event(ent) if ahead else None
         rc = 0
         if ahead and early:

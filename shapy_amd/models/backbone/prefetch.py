@@ -73,7 +73,16 @@ class ProloguePrefetch:
 
     @staticmethod
     def key(x, sk):
-        return (x.data_ptr(), tuple(x.shape), x._version, sk)
+        # (an inference tensor has no version counter -- reading it raises; such tensors are never stashed, `usable`)
+        return (x.data_ptr(), tuple(x.shape), None if x.is_inference() else x._version, sk)
+
+    def drop(self):
+        """Forget the stashed prologue (the next forward runs in full).  For callers that WRITE the handed-over
+        tensor behind torch's back between the two calls: the stash is recognised by (address, shape, torch
+        version counter), and a raw-pointer kernel, a DLPack alias or another process's copy engine changes the
+        bytes without bumping the counter (HighResolutionNet.drop_prefetch, tests/test_gpu_parity.py::
+        test_hrnet_prefetch_stash_rules)."""
+        self.pending = None
 
     def take(self, x, eng, ent, sk):
         """The stashed prologue of exactly this input, or None (the stash is dropped either way).  The stash holds
@@ -91,11 +100,23 @@ class ProloguePrefetch:
     @staticmethod
     def usable(nx, x):
         return (torch.is_tensor(nx) and nx.is_cuda and nx.device == x.device and nx.dtype == torch.float32
-                and nx.shape == x.shape and nx.is_contiguous())
+                and nx.shape == x.shape and nx.is_contiguous() and not nx.is_inference())
+
+    @staticmethod
+    def second_workspace(ent, need, device):
+        """The other workspace and its split-K arrival counters, allocated (and the counters ZEROED, on the caller's
+        stream) before `ready_event` is recorded: the side stream waits for that event only, so a memset enqueued
+        behind it could still be pending when the first prologue reaches a split-K layer."""
+        other = 1 - ent['cur']
+        if ent['ws'][other] is None:
+            ent['ws'][other] = torch.empty(max(need, ent['ws'][0].numel()), dtype=torch.uint8, device=device)
+            c0 = ent['cnt'][0]                     # the second workspace has arrival counters of its own
+            ent['cnt'][other] = None if c0 is None else torch.zeros_like(c0)
+            ent['done'] = [torch.cuda.Event(), torch.cuda.Event()]
 
     def ready_event(self, ent):
         """Recorded on the caller's stream BEFORE the rest of the running batch is issued: the next input is
-        there and the other workspace's last user (the batch before this one) is done."""
+        there, the other workspace's last user (the batch before this one) is done and its counters are zero."""
         if 'ev' not in ent:
             ent['ev'] = torch.cuda.Event()
         ent['ev'].record()
@@ -103,11 +124,7 @@ class ProloguePrefetch:
 
     def issue(self, lib, run, eng, ent, nx, ev, sk, need, cut):
         other = 1 - ent['cur']
-        if ent['ws'][other] is None:
-            ent['ws'][other] = torch.empty(max(need, ent['ws'][0].numel()), dtype=torch.uint8, device=nx.device)
-            c0 = ent['cnt'][0]                     # the second workspace has arrival counters of its own
-            ent['cnt'][other] = None if c0 is None else torch.zeros_like(c0)
-            ent['done'] = [torch.cuda.Event(), torch.cuda.Event()]
+        assert ent['ws'][other] is not None, 'second_workspace() runs before ready_event()'
         side = self.side_stream(lib, nx.device)
         side.wait_event(ev)
         # the side stream reads / writes these after the caller may have dropped them

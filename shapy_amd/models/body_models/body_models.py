@@ -265,6 +265,10 @@ class SMPLX(VersionedWeights, nn.Module):
         _lib.require_cuda(self.shapedirs, 'SMPLX buffers')
         parts = ((global_rot, 1), (body_pose, self.NUM_BODY_JOINTS), (jaw_pose, 1), (leye_pose, 1),
                  (reye_pose, 1), (left_hand_pose, self.NUM_HAND_JOINTS), (right_hand_pose, self.NUM_HAND_JOINTS))
+        # the reference views every part as reshape(-1, n, 3, 3) (body_models.py:676-690): a part given as
+        # [B * n, 3, 3] or [B, n * 9] is the same pose
+        parts = tuple((p_ if p_ is None or (p_.dim() == 4 and tuple(p_.shape[1:]) == (n, 3, 3))
+                       else p_.reshape(-1, n, 3, 3), n) for p_, n in parts)
         B = 1
         for var in (betas, transl, expression):
             if var is not None and var.shape[0] > B:
@@ -294,7 +298,7 @@ class SMPLX(VersionedWeights, nn.Module):
                         break
                     expect *= t.shape[d]
             if not ok:
-                t = t.reshape(t.shape[0], *inner).to(dtype=torch.float32, device=device).contiguous()
+                t = t.reshape(-1, *inner).to(dtype=torch.float32, device=device).contiguous()
                 keep.append(t)
             if t.shape[0] == B and B > 1:
                 return t.data_ptr(), t.stride(0)

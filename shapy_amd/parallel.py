@@ -59,27 +59,33 @@ class BetasGatherer:
         call.  The compute stream never queues behind the collective, i.e. never behind the slowest
         rank: lane 1 gets its first op of the next forward ~1.4 ms into it (transition1), by which
         time the latency-bound gather has long finished.
-        'rccl' = round 4: the same direct call on the CALLER's stream (every rank's next step queues
-        behind the collective); 'work' = c10d, async_op=True from the caller's stream, the Work handle
-        joined at the next call; 'side' = rounds 1-3: c10d on a private side stream.
-        SHAPY_GATHER_MODE overrides the default."""
+        'work' = the fallback: torch.distributed's NCCL backend, async_op=True from the caller's stream,
+        the Work handle joined at the next call (what every rank takes together when the direct
+        communicator cannot be built; selectable for A/B runs).  The compute-stream and private-side-
+        stream forms of rounds 1-4 lost on one GPU (profiles/r04j_*, r05c_*) and are gone.
+        SHAPY_GATHER_MODE overrides the default.
+        ``last_join_wait_ms`` (after ``wait(measure=True)``): how long the host found the lane's `done`
+        event still pending -- at N > 1 the only evidence of a lane-1 stall behind a slow rank; bench.py
+        reports its maximum over the timed steps."""
         import os
         self.group = group
         self.world = world if world is not None else (
             dist.get_world_size(group) if dist.is_initialized() else 1)
         self.force = bool(force)
         self.mode = mode or os.environ.get('SHAPY_GATHER_MODE', 'lane')
-        if self.mode not in ('lane', 'rccl', 'work', 'side'):
+        if self.mode not in ('lane', 'work'):
             raise ValueError(f'unknown gather mode {self.mode!r}')
-        self._comm = None             # modes 'lane' / 'rccl': shapy_amd.rccl.RcclComm, created on first use
-        self._stream = None
+        self._comm = None             # mode 'lane': shapy_amd.rccl.RcclComm, created on first use
+        self.last_join_wait_ms = 0.0
         self._lane = None             # mode 'lane': the executor's lane-1 stream (torch.cuda.ExternalStream)
         self._pending = None          # (out, event | Work | None) of the gather still in flight
         self.issued = 0
         self.deferred_waits = 0       # waits that were served by a LATER call (the overlap)
 
-    def wait(self):
-        """Makes the current stream wait for the gather in flight (if any); returns its result."""
+    def wait(self, measure=False):
+        """Makes the current stream wait for the gather in flight (if any); returns its result.
+        measure: the HOST also waits for the lane's `done` event and records how long that took
+        (diagnostics only: it serialises the host with the device)."""
         if self._pending is None:
             return None
         out, h = self._pending[:2]
@@ -87,6 +93,11 @@ class BetasGatherer:
         if h is None:
             pass
         elif isinstance(h, torch.cuda.Event):
+            if measure:
+                import time
+                t0 = time.perf_counter()
+                h.synchronize()
+                self.last_join_wait_ms = (time.perf_counter() - t0) * 1e3
             torch.cuda.current_stream().wait_event(h)
         else:
             h.wait()                  # c10d Work: the CURRENT STREAM waits for the RCCL stream
@@ -101,37 +112,20 @@ class BetasGatherer:
         local = local.contiguous()
         out = local.new_empty((self.world * local.shape[0],) + tuple(local.shape[1:]))
         self.issued += 1
-        if local.is_cuda and self.mode in ('lane', 'rccl'):
+        if local.is_cuda and self.mode == 'lane':
             if self._comm is None and not self._init_rccl():
                 return self._call_c10d(local, out)          # every rank fell back to mode 'work'
-            if self.mode == 'rccl':
-                # on the CALLER's stream: no event -- the gather is one more kernel behind the step's tail
-                out = self._comm.all_gather(local, out=out)
-                self._pending = (out, None, local)
-            else:
-                # on the executor's lane-1 stream, behind the producer of `local`; joined by the next call
-                lane = self._lane_stream(local.device)
-                ready = torch.cuda.Event()
-                ready.record(torch.cuda.current_stream(local.device))
-                lane.wait_event(ready)
-                self._comm.all_gather(local, stream=lane.cuda_stream, out=out)
-                done = torch.cuda.Event()
-                done.record(lane)
-                self._pending = (out, done, local)     # `local` / `out` stay referenced until the join
-        elif local.is_cuda and self.mode == 'work':
-            work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
-            self._pending = (out, work, local)       # `local` stays referenced until the join
+            # on the executor's lane-1 stream, behind the producer of `local`; joined by the next call
+            lane = self._lane_stream(local.device)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(local.device))
+            lane.wait_event(ready)
+            self._comm.all_gather(local, stream=lane.cuda_stream, out=out)
+            done = torch.cuda.Event()
+            done.record(lane)
+            self._pending = (out, done, local)     # `local` / `out` stay referenced until the join
         elif local.is_cuda:
-            if self._stream is None:
-                self._stream = torch.cuda.Stream()
-            self._stream.wait_stream(torch.cuda.current_stream())    # `local` is produced there
-            with torch.cuda.stream(self._stream):
-                dist.all_gather_into_tensor(out, local, group=self.group)
-                ev = torch.cuda.Event()
-                ev.record(self._stream)
-            local.record_stream(self._stream)
-            out.record_stream(self._stream)
-            self._pending = (out, ev)
+            return self._call_c10d(local, out)
         else:
             chunks = list(out.chunk(self.world, dim=0))
             dist.all_gather(chunks, local, group=self.group)
@@ -205,8 +199,12 @@ class BetasGatherer:
         return False
 
     def _fallback_group(self):
+        # only the members of self.group are here (the agreement ran over it): for a real subgroup the
+        # creation must not wait for the other ranks of the world
         ranks = None if self.group is None else dist.get_process_group_ranks(self.group)
-        return dist.new_group(ranks=ranks, backend='nccl')
+        if ranks is None or len(ranks) == dist.get_world_size():
+            return dist.new_group(ranks=ranks, backend='nccl')
+        return dist.new_group(ranks=ranks, backend='nccl', use_local_synchronization=True)
 
     def _call_c10d(self, local, out):
         work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
@@ -219,7 +217,7 @@ class BetasGatherer:
         return out
 
     def close(self):
-        """Joins the gather in flight and destroys the RCCL communicator of mode 'rccl' (call before
+        """Joins the gather in flight and destroys the direct RCCL communicator (call before
         the process group goes away; idempotent)."""
         self.wait()
         if self._comm is not None:

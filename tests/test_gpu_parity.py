@@ -943,6 +943,97 @@ def test_full_forward_next_images_bit_identical(network):
         bb.conv_algo = 'direct'
 
 
+@pytest.mark.parametrize('B', [32, 16])
+def test_full_forward_mid_batch_buckets_with_next_images_vs_oracle(network, B):
+    """The batch buckets between the reference goldens (B <= 4) and the headline (B = 64): B = 32 (split-K policy
+    {(384,4): 4, (192,16): 2} + implicit-GEMM splits; stem + layer1 of the next batch behind the rest) and B = 16
+    (same plan bucket, EARLY prologue: stem + layer1 + stage 2 issued in front of the running batch) -- the plans
+    configs[2]'s per-GPU shard and evaluate.py's batches take.  f32, default algorithm, @224, in a pipelined loop
+    (next_images), every output of the SECOND step (whose prologue ran under the first) against the CPU oracle
+    at 1e-4 (iterative_regressor.py:623-870)."""
+    import __graft_entry__ as ge
+    from shapy_amd.models.backbone import hrnet as hrnet_mod
+    from shapy_amd.utils import synthetic as syn
+    bb = network.backbone
+    keep = (bb.multi_stream, bb.compute_dtype, bb.conv_algo)
+    bb.multi_stream, bb.compute_dtype, bb.conv_algo = True, 'f32', hrnet_mod.DEFAULT_CONV_ALGO
+    xs_np = [syn.synthetic_images(B, 224, 300 + B + i) for i in range(2)]
+    xs = [torch.from_numpy(a).cuda() for a in xs_np]
+    try:
+        with torch.no_grad():
+            used0 = bb._prefetch.used
+            network(xs[0], None, next_images=xs[1])
+            out = network(xs[1], None, next_images=xs[0])
+            assert bb._prefetch.used - used0 == 1, 'the second step did not run on the prefetched prologue'
+            bb.drop_prefetch()
+        torch.cuda.synchronize()
+    finally:
+        bb.multi_stream, bb.compute_dtype, bb.conv_algo = keep
+    ref = ge.oracle_forward(xs_np[1])
+    st, rs = out['stage_02'], ref['stages'][-1]
+    errs = {
+        'features': np.abs(out['features'].cpu().numpy() - ref['features']).max(),
+        'betas': np.abs(st['betas'].cpu().numpy() - rs['betas']).max(),
+        'vertices': np.abs(st['vertices'].cpu().numpy() - rs['vertices']).max(),
+        'joints': np.abs(st['joints']._t.cpu().numpy() - rs['joints']).max(),
+    }
+    for k in ('mass', 'height', 'chest', 'waist', 'hips'):
+        errs['meas_' + k] = np.abs(out['measurements'][k].cpu().numpy() - ref['measurements'][k]).max()
+    for k, v in errs.items():
+        print(f'B={B} pipelined {k:14s} {v:.3e}')
+    bad = {k: v for k, v in errs.items() if not v < 1e-4}
+    assert not bad, bad
+
+
+def test_hrnet_prefetch_stash_rules(network):
+    """What makes a stashed prologue stale (prefetch.py): an in-place torch write bumps the version counter ->
+    ignored; a write BEHIND torch's back (here: through a DLPack alias, which has a version counter of its own)
+    is invisible -> the documented rule is drop_prefetch() before such a write, after which the forward runs in
+    full; tensors created under inference_mode have no version counter -> never stashed, no exception."""
+    from torch.utils import dlpack
+    from shapy_amd.models.backbone import hrnet as hrnet_mod
+    from shapy_amd.utils import synthetic as syn
+    bb = network.backbone
+    keep = (bb.multi_stream, bb.compute_dtype, bb.conv_algo)
+    bb.multi_stream, bb.compute_dtype, bb.conv_algo = True, 'f32', hrnet_mod.DEFAULT_CONV_ALGO
+    a = torch.from_numpy(syn.synthetic_images(4, 96, 11)).cuda()
+    b = torch.from_numpy(syn.synthetic_images(4, 96, 12)).cuda()
+    try:
+        with torch.no_grad():
+            plain = lambda t: bb(t.clone())['concat'].clone()
+            # (1) in-place torch write: recognised
+            used = bb._prefetch.used
+            bb(a, prefetch=b)
+            b.mul_(0.5)
+            out = bb(b)['concat'].clone()
+            assert bb._prefetch.used == used and torch.equal(out, plain(b))
+            # (2) write through an alias torch does not track + drop_prefetch(): full forward, right answer
+            bb(a, prefetch=b)
+            alias = dlpack.from_dlpack(dlpack.to_dlpack(b))
+            bb.drop_prefetch()
+            alias.add_(0.25)
+            torch.cuda.synchronize()
+            out = bb(b)['concat'].clone()
+            assert bb._prefetch.used == used and torch.equal(out, plain(b))
+            # (3) untouched: the stash is used and bit-identical
+            bb(a, prefetch=b)
+            out = bb(b)['concat'].clone()
+            assert bb._prefetch.used == used + 1 and torch.equal(out, plain(b))
+        # (4) inference tensors: no version counter; forward works, nothing is stashed
+        with torch.inference_mode():
+            ai, bi = a.clone(), b.clone()
+            issued = bb._prefetch.issued
+            o1 = bb(ai, prefetch=bi)['concat'].clone()
+            o2 = bb(bi)['concat'].clone()
+            assert bb._prefetch.issued == issued
+        with torch.no_grad():
+            assert torch.equal(o1, plain(a)) and torch.equal(o2, plain(b))
+        torch.cuda.synchronize()
+    finally:
+        bb.drop_prefetch()
+        bb.multi_stream, bb.compute_dtype, bb.conv_algo = keep
+
+
 def test_hrnet_head_gemms_on_bf16x6_vs_f32_kernel(network):
     """Opt-in (x6_gemm_min_batch = 64): the head's fifteen wide 1x1 GEMMs on the bf16 matrix cores
     (SHAPY_TILE_X6 in a float32 plan: float32 tensors, exact 3-way bf16 split, f32 accumulate).  Against the
@@ -1100,7 +1191,7 @@ def test_full_forward_vs_reference_golden(network, golden_dir, cdt):
     for k, v in errs.items():
         print(f'{k:24s} {v:.3e}')
     assert st['faces'].shape == (20908, 3)
-    bad = {k: v for k, v in errs.items() if not v < (2e-4 if k == 'meas_mass' else 1e-4)}
+    bad = {k: v for k, v in errs.items() if not v < 1e-4}
     assert not bad, bad
 
 
@@ -1169,7 +1260,7 @@ def test_full_forward_256_vs_reference_golden(network, golden_dir):
         errs['meas_' + k] = np.abs(out['measurements'][k].cpu().numpy() - g['meas_' + k]).max()
     for k, v in errs.items():
         print(f'{k:24s} {v:.3e}')
-    bad = {k: v for k, v in errs.items() if not v < (2e-4 if k == 'meas_mass' else 1e-4)}
+    bad = {k: v for k, v in errs.items() if not v < 1e-4}
     assert not bad, bad
 
 
@@ -1224,7 +1315,11 @@ def test_smplx_forward_odd_batches_and_full_pose_vs_oracle(network, B):
                           reye_pose=eye(1), left_hand_pose=eye(15), right_hand_pose=eye(15), betas=bt,
                           get_skin=True, return_shaped=True, return_full_pose=True)
         c = network.model(global_rot=r[:, :1], body_pose=r[:, 1:], betas=bt[:1], get_skin=True)
+        # parts whose leading dimension is not the batch: the reference views them as reshape(-1, n, 3, 3)
+        d = network.model(global_rot=r[:, :1].reshape(B, 3, 3), body_pose=r[:, 1:].reshape(B * 21, 3, 3), betas=bt,
+                          get_skin=True, return_shaped=True)
     torch.cuda.synchronize()
+    assert torch.equal(a['vertices'], d['vertices']) and torch.equal(a['joints']._t, d['joints']._t)
     for out in (a, b):
         assert np.abs(out['vertices'].cpu().numpy() - ref['vertices']).max() < 1e-4
         assert np.abs(out['joints']._t.cpu().numpy() - ref['joints']).max() < 1e-4
@@ -1476,7 +1571,7 @@ def test_full_forward_bs64_vs_oracle(network, cdt):
     for k, v in errs.items():
         print(f'bs64 {cdt} {k:14s} {v:.3e}')
     assert int(network.body_measurements.last_overflow.item()) == 0
-    bad = {k: v for k, v in errs.items() if not v < (2e-4 if k == 'meas_mass' else 1e-4)}
+    bad = {k: v for k, v in errs.items() if not v < 1e-4}
     assert not bad, bad
 
 
@@ -1659,7 +1754,7 @@ def _nccl_one_rank_worker(port, q):
     dist.init_process_group('nccl', init_method='env://')
     try:
         ok = {}
-        for mode in ('lane', 'rccl', 'work', 'side'):
+        for mode in ('lane', 'work'):
             gat = parallel.BetasGatherer(1, force=True, mode=mode)
             side = torch.cuda.Stream()
             with torch.cuda.stream(side):              # a non-default caller stream, as in serving
@@ -1672,7 +1767,7 @@ def _nccl_one_rank_worker(port, q):
             gat.close()
         # the direct communicator "fails" on every rank -> the gatherer agrees on c10d (mode 'work')
         os.environ['SHAPY_RCCL_FORCE_FAIL'] = '1'
-        gat = parallel.BetasGatherer(1, force=True, mode='rccl')
+        gat = parallel.BetasGatherer(1, force=True, mode='lane')
         x = torch.randn(8, 10, device='cuda')
         got = gat.gather(x)
         torch.cuda.synchronize()
@@ -1685,10 +1780,9 @@ def _nccl_one_rank_worker(port, q):
 
 def test_rccl_forced_gather_one_rank_both_modes():
     """bench.py --force-gather's path: a world-size-1 RCCL group on ONE GPU runs the collective of the
-    N-rank path in all four issue modes of BetasGatherer ('lane', the default: ncclAllGather called
-    directly on the executor's lane-1 stream and joined one step later, shapy_amd/rccl.py; 'rccl': the
-    same call on the caller's stream; 'work': c10d async collective from the caller's stream; 'side':
-    c10d on a private side stream)."""
+    N-rank path in both issue modes of BetasGatherer ('lane', the default: ncclAllGather called
+    directly on the executor's lane-1 stream and joined one step later, shapy_amd/rccl.py; 'work': the
+    fallback, c10d async collective from the caller's stream) and the agreed fallback itself."""
     _need_gpu()
     import socket
     import torch.multiprocessing as mp
@@ -1701,7 +1795,7 @@ def test_rccl_forced_gather_one_rank_both_modes():
     p.start()
     res = q.get(timeout=300)
     p.join(timeout=60)
-    assert res == {'lane': True, 'rccl': True, 'work': True, 'side': True, 'fallback': True}, res
+    assert res == {'lane': True, 'work': True, 'fallback': True}, res
 
 
 def test_rccl_allgather_two_ranks():
