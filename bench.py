@@ -159,11 +159,14 @@ def pmc_traffic(batch, size, dtype='f32', algo='direct', any_algo=False):
                    h['fetch_x2_corrected'], 'conv_algo': h.get('algo', 'direct'),
                    'source': osp.relpath(f, ROOT)}
             m = d.get('mfma')
+            out['pmc_plan'] = d.get('plan', 'bench.py --single-stream')
             if m and m.get('GRBM_GUI_ACTIVE_sum_over_8_xcd'):
-                # matrix-core busy share of all SIMD cycles over the same (single-stream) pass:
-                # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE summed over the 8 XCDs x 128 SIMDs each)
+                # matrix-core busy share of all SIMD cycles over the PROFILED pass (dispatches serialised by the
+                # counter collection): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE summed over 8 XCDs x 128 SIMDs)
                 out['mfma_busy_frac_of_simd_cycles'] = (
                     m['SQ_VALU_MFMA_BUSY_CYCLES_sum'] / (m['GRBM_GUI_ACTIVE_sum_over_8_xcd'] * 128.0))
+            if m and m.get('busy_cycles_per_forward'):
+                out['mfma_busy_cycles_per_forward'] = m['busy_cycles_per_forward']
             return out
     return None
 
@@ -905,6 +908,17 @@ def run_regressor(args, rank, world, local_rank):
                                  f'count with the matrix-pipe time they need: bf16 FLOPs x f32 peak / bf16 peak '
                                  f'(= {X6_F32_PIPE_EQUIV:.4f} per float32 FLOP)'},
                      'ms_per_launch_group': backbone_ms,
+                     # north_star's "MFMA utilisation": matrix-pipe busy cycles of one forward from the counter
+                     # (SQ_VALU_MFMA_BUSY_CYCLES, PMC pass over the four-lane plan: traffic_detail.pmc_plan) over the
+                     # SIMD cycles of the MEASURED step period of THIS run -- at the nominal 2.4 GHz (a lower bound:
+                     # these boxes hold ~2.06-2.1 GHz under MFMA load) and at 2.1 GHz
+                     'mfma_busy': None if not (traffic and traffic.get('mfma_busy_cycles_per_forward')) else {
+                         'busy_cycles_per_forward': traffic['mfma_busy_cycles_per_forward'],
+                         'frac_of_simd_cycles_at_2.4GHz': traffic['mfma_busy_cycles_per_forward'] /
+                                                         (1024 * 2.4e9 * backbone_ms * 1e-3),
+                         'frac_of_simd_cycles_at_2.1GHz': traffic['mfma_busy_cycles_per_forward'] /
+                                                         (1024 * 2.1e9 * backbone_ms * 1e-3),
+                         'source': traffic['source'], 'pmc_plan': traffic.get('pmc_plan')},
                      'duration': ('step period (pipelined: the next batch\'s stem + layer1 run under this batch\'s '
                                   f'head on a side stream; HIP events around the call see only the rest: {call_ms:.3f} ms)'
                                   if backbone_ms != call_ms else 'HIP events around the backbone call'),

@@ -21,7 +21,6 @@ SOURCES = {
     'conv_x6.hip': [],
     'conv_wino.hip': [],
     'conv_wino4.hip': [],
-    'conv_wino4q.hip': [],
     'conv_wino4g.hip': [],
     'hrnet_ops.hip': [],
     'body.hip': [],

@@ -47,7 +47,6 @@ struct ConvK {
   int flat;                     // bf16, Cin % 32 != 0: flat-K kernel
   int pd3;                      // implicit GEMM: three chunks of global loads in flight
   int ups_split;                // upsample-scatter layers: workgroups per tile, each scatters ups / ups_split rows
-  int w4_legacy;                // A/B knob (tile flag 0x1000000): F(4x4) on the 3 + 1-wave kernel of conv_wino4.hip
   int ksplit;                   // K slices per output tile (SHAPY_TILE_KSPLIT), 1 = none: F(4x4) and implicit GEMM
   void *split_ws;               // ... their slab (ShapyConv.split_ws), the bytes the launch uses of it ...
   unsigned split_bytes;
@@ -62,8 +61,6 @@ int conv2d_wino(ConvK k, int tm, hipStream_t s);
 // Winograd F(4x4,3x3) path (conv_wino4.hip): k.wgt2 holds [36][Cin/16][Cout][16] filters
 int conv2d_wino4(ConvK k, hipStream_t s);
 bool conv_wino4_fits(const ConvK &k);
-// ... its four-multiplying-wave form (conv_wino4q.hip; Cout % 48 == 0), k prepared by conv2d_wino4
-int conv2d_wino4q_launch(const ConvK &k, int S, hipStream_t s);
 // persistent grouped F(4x4) launch (conv_wino4g.hip): up to 4 layers
 int conv2d_wino4_group(const ConvK *ks, int n, hipStream_t s);
 

@@ -487,7 +487,6 @@ int conv_prepare(const ShapyConv &d, ConvK &k, int *empty) {
   k.swz = (d.tile & 0x400) ? 0 : 1;
   k.no_nslab = (d.tile & 0x10000) ? 1 : 0;
   k.no_allk = (d.tile & 0x20000) ? 1 : 0;
-  k.w4_legacy = (d.tile & 0x1000000) ? 1 : 0;
   // F(4x4) split-K (conv_wino4.hip): SHAPY_TILE_W4_KSPLIT(S) in the tile word, slab + counters from
   // the caller
   k.ups_split = 1;
@@ -518,7 +517,7 @@ int conv2d(const ShapyConv &d, hipStream_t s) {
       if (d.dtype != SHAPY_DTYPE_F32 || !conv_wino_eligible(k)) return SHAPY_EINVAL;
       return conv2d_wino4(k, s);
     }
-    if (d.dtype != SHAPY_DTYPE_F32 || (k.Cout % 48 && k.Cout % 64)) return SHAPY_EINVAL;
+    if (d.dtype != SHAPY_DTYPE_F32 || k.Cout % 48) return SHAPY_EINVAL;
     // tensors beyond the kernel's 1 GiB offset scheme (B > 334 at 224x224) or with rows that are
     // not 16-byte aligned: the direct kernel on
     // the untransformed weights, which every layer carries -- slower, same convolution

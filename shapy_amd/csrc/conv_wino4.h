@@ -107,7 +107,7 @@ struct Wino4Split {
 // tile: the lane's tile (m_blk + l15); col4: its first output channel (n0 + 4 g4); g4 = lane >> 4.
 // S == 1: no split (sp / ticket unused).
 // xf(s): fills s[i][b] = (M A)[i][b], the accumulators transformed along x -- called exactly once on every
-// path (the four-wave kernel of conv_wino4q.hip completes rows 4 / 5 through an LDS exchange with a
+// path (the four-wave kernel of conv_wino4.hip completes rows 4 / 5 through an LDS exchange with a
 // workgroup barrier inside).
 template <int S, typename XF>
 __device__ __forceinline__ void wino4_epilogue_x(const Wino4Epi &e, const Wino4Split &sp, int ticket,

@@ -256,14 +256,6 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self.conv_algo = os.environ.get('SHAPY_CONV_ALGO', DEFAULT_CONV_ALGO)
         self.wino_min_hw = 14
         self.wino4_min_hw = int(os.environ.get('SHAPY_WINO4_MIN_HW', DEFAULT_WINO4_MIN_HW))
-        #: conv_algo='winograd4': output widths that are a multiple of 64 but not of 48 and may run on
-        #: the 64-channel variant of the F(4x4) kernel (four multiplying waves, one workgroup per CU)
-        #: instead of F(2x2).  Empty by default: on layer1's 64 -> 64 it is 15 % faster in isolation
-        #: (88 vs 104 us) but the forward does not move (profiles/r04t_*); on the head's 512 -> 512
-        #: @7x7 it loses without a K split (131 vs 100 us).  (SHAPY_WINO4_N64="64,512" for A/B runs.)
-        #: A/B knob: input-channel classes that stay on the 3 + 1-wave F(4x4) kernel (SHAPY_W4_LEGACY="192,384")
-        self.wino4_legacy_cin = tuple(int(c) for c in os.environ.get('SHAPY_W4_LEGACY', '').split(',') if c)
-        self.wino4_n64 = tuple(int(c) for c in os.environ.get('SHAPY_WINO4_N64', '').split(',') if c)
         #: F(4x4) split-K: {(Cin, most 4x4 tiles per image): S} -- a layer with that many input channels
         #: on a map of at most that many tiles runs S workgroups per output tile, each over Cin / S
         #: channels (csrc/conv_wino4.hip).  The policy is chosen per BATCH BUCKET (wino4_ksplit_by_batch:
@@ -453,8 +445,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         return self.conv_algo in ('winograd', 'winograd4') or min(Hi, Wi) >= self.wino_min_hw
 
     def _use_wino4(self, ks, st, pad, cin, cout, Hi, Wi, ups):
-        # 64-channel N tiles (four multiplying waves, one workgroup per CU): only on request
-        if cout % 48 and cout not in self.wino4_n64:
+        if cout % 48:                 # the F(4x4) kernel's N tile (layer1's 64 -> 64, the head's 512 -> 512: F(2x2))
             return False
         return (self.conv_algo == 'winograd4' and min(Hi, Wi) >= self.wino4_min_hw
                 and winograd.eligible4(ks, st, pad, cin, cout, ups))
@@ -551,7 +542,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                 wino_off = P.add_weights(self._xform(name, 2, w))
             elif not (bf16 or x6) and self._use_wino4(ks, st, pad, cin_p, cout_p, Hi, Wi, ups):
                 wino_off = P.add_weights(self._xform(name, 4, w))
-                wino_flag = _lib.TILE_WINO4 | (0x1000000 if cin_p in self.wino4_legacy_cin else 0)
+                wino_flag = _lib.TILE_WINO4
                 # split-K (never inside a persistent grouped launch, which has no such form)
                 sl = 1 if group_member else self._ksplit(cin_p, Hi, Wi)
                 if sl > 1:
@@ -797,7 +788,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         pol = self.ksplit_policy(B) if self.compute_dtype == 'f32' else {}
         dpol = self.direct_ksplit_policy(B, bf16) if self.compute_dtype in ('f32', 'bf16') else {}
         key_w = (H, W, str(device), self.compute_dtype, self.conv_algo, self.wino_min_hw,
-                 self.wino4_min_hw, self._group_on(), self._dag_eff, tuple(self.wino4_n64),
+                 self.wino4_min_hw, self._group_on(), self._dag_eff,
                  tuple(sorted(self.layer_algo.items())), self.tile_flags,
                  tuple(sorted(self.tile_overrides.items())))
         lx6 = self.compute_dtype == 'f32' and 0 < self.x6_gemm_min_batch <= (B or 0)

@@ -73,10 +73,9 @@ AT4 = np.array([[1.0, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0],
 
 def eligible4(ksize, stride, pad, cin, cout, ups=1):
     """Layers conv_wino4.hip takes: 3x3 / stride 1 / pad 1, 16-channel K chunks, 48-channel N
-    tiles (three multiplying waves of 16 channels + one staging wave per workgroup) or, when Cout
-    is a multiple of 64 only, 64-channel N tiles (four multiplying waves)."""
+    tiles (four waves, each 27 of the 108 position x channel-group items of a chunk)."""
     return (ksize == 3 and stride == 1 and pad == 1 and ups == 1 and cin % 16 == 0
-            and (cout % 48 == 0 or cout % 64 == 0))
+            and cout % 48 == 0)
 
 
 def transform_filters4(w_ohwi):

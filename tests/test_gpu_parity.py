@@ -218,10 +218,8 @@ WINO4_CASES = [
     (1, 7, 7, 384, 384, True, True),       # N-slab order (transformed filters > 2 MB)
     (5, 4, 4, 16, 48, False, False),       # one tile per image, 5 of 16 tiles live
     (1, 3, 3, 16, 48, True, False),        # smaller than one tile
-    (2, 12, 20, 64, 64, True, True),       # 64-channel N tile: four multiplying waves, unrolled 4 chunks
-    (1, 7, 7, 32, 128, True, False),       # ... two N tiles, generic chunk loop
-    (2, 56, 56, 64, 64, False, True),      # layer1's 3x3 class
-    (1, 7, 7, 512, 512, False, True),      # the head's 3x3 class (N-slab order)
+    (2, 12, 20, 64, 96, True, True),       # four chunks through the generic loop, two N tiles
+    (1, 9, 9, 80, 48, False, True),        # five chunks (odd count: both V buffers end up as the exchange buffer)
 ]
 
 
@@ -235,8 +233,7 @@ WINO4_SPLIT_CASES = [
     (64, 14, 14, 192, 192, True, True, 2),     # the 14x14 branch: KC = 6
     (8, 14, 14, 192, 192, True, True, 4),      # ... small-batch policy: KC = 3, four slices
     (8, 28, 28, 96, 96, True, True, 2),        # the 28x28 branch, small-batch policy: KC = 3, two slices
-    (5, 7, 7, 512, 512, False, True, 2),       # 64-channel N tile (four multiplying waves), 16 chunks per slice
-    (5, 7, 7, 512, 512, True, True, 4),
+    (5, 7, 7, 256, 96, False, True, 2),        # 8 chunks per slice through the generic loop
 ]
 
 
@@ -360,7 +357,7 @@ def test_conv_winograd4_split_k_refusals(lib):
 
 @pytest.mark.parametrize('case', WINO4_CASES, ids=[str(c) for c in WINO4_CASES])
 def test_conv_winograd4_kernel_vs_float64(lib, case):
-    """csrc/conv_wino4.hip (F(4x4,3x3), staging wave + three multiplying waves) through
+    """csrc/conv_wino4.hip (F(4x4,3x3), four multiplying waves that stage a quarter of every chunk each) through
     shapy_conv2d (ShapyConv.wgt_wino + SHAPY_TILE_WINO4) against float64, next to the direct
     kernel on the same operands."""
     B, H, W, Cin, Cout, use_res, relu = case
@@ -410,8 +407,8 @@ def test_conv_winograd4_concat_offset_and_refusals(lib):
     ref = _conv_ref(x, w, b, before[..., 16:64], True, 1, 1)
     assert (big[..., 16:64].cpu().double() - ref).abs().max().item() < 3e-5
     assert torch.equal(big[..., :16], before[..., :16]) and torch.equal(big[..., 64:], before[..., 64:])
-    # Cout = 80 has neither a 48- nor a 64-channel N tiling; stride 2 is not a Winograd layer
-    for cout, stride in ((80, 1), (48, 2)):
+    # Cout = 80 / 64 have no 48-channel N tiling (64 -> 64 is an F(2x2) layer); stride 2 is not a Winograd layer
+    for cout, stride in ((80, 1), (64, 1), (48, 2)):
         w2 = torch.randn(cout, 3, 3, 32, generator=g).cuda()
         d = _lib.ShapyConv()
         out = torch.empty(2, 10, 10, cout, device='cuda')

@@ -413,15 +413,6 @@ def test_winograd4_plan_filters_and_kernel_indexing(hrnet):
     w4 = [o for o in P.ops if o['type'] == 0 and o['tile'] & _lib.TILE_WINO4]
     assert all(min(o['Hi'], o['Wi']) >= hrnet.wino4_min_hw and o['Cout'] % 48 == 0 and
                o['wino_off'] >= 0 for o in w4)
-    # the 64-channel N tile (opt-in per output width): layer1's four 64 -> 64 @56x56 convs join
-    hrnet.conv_algo, hrnet.wino4_n64 = 'winograd4', (64,)
-    try:
-        P64 = hrnet._build_plan(224, 224)
-    finally:
-        hrnet.conv_algo, hrnet.wino4_n64 = 'winograd', ()
-    assert count(P64) == (189, 29)
-    assert sorted(o['name'] for o in P64.ops if o['type'] == 0 and o['tile'] & _lib.TILE_WINO4
-                  and o['Cout'] % 48) == [f'layer1.{i}.conv2' for i in range(4)]
     assert not any(o['tile'] & _lib.TILE_WINO4 for o in hrnet._build_plan(224, 224).ops)
     hrnet.conv_algo, hrnet.wino4_min_hw = keep
     rng = np.random.default_rng(0)

@@ -71,7 +71,7 @@ def main():
             d = _lib.ShapyConv()
             if tile.startswith('autok'):               # implicit GEMM, automatic tile, split-K with S slices
                 pass
-            elif tile in ('wino4', 'wino4old') or tile.startswith('wino4k'):   # Winograd F(4x4,3x3) (conv_wino4.hip); wino4kS: split-K, S slices
+            elif tile == 'wino4' or tile.startswith('wino4k'):   # Winograd F(4x4,3x3) (conv_wino4.hip); wino4kS: split-K, S slices
                 from shapy_amd.utils import winograd
                 if args.dtype != 'f32' or not winograd.eligible4(ks, st, pad, Cin, Cout, ups) \
                         or min(Hi, Wi) < args.wino4_min_hw:
@@ -104,9 +104,8 @@ def main():
                 d.split_ws, d.split_cnt = split_ws.data_ptr(), split_cnt.data_ptr()
                 d.split_kib, d.split_cnt_n = split_ws.numel() * 4 // 1024, split_cnt.numel()
                 d.tile = 0x2000 | _lib.tile_w4_ksplit(S)
-            elif tile.startswith('wino4k'):          # wino4kS: new kernel; wino4koS: the 3 + 1-wave kernel
-                old = tile[6] == 'o'
-                S = int(tile[7:] if old else tile[6:])
+            elif tile.startswith('wino4k'):
+                S = int(tile[6:])
                 if (Cin // 16) % S:
                     continue
                 slab, ncnt = _lib.w4_split_sizes(Hi, Wi, Cout, S)
@@ -114,10 +113,10 @@ def main():
                 split_cnt = torch.zeros(ncnt * B, dtype=torch.int32, device='cuda')
                 d.split_ws, d.split_cnt = split_ws.data_ptr(), split_cnt.data_ptr()
                 d.split_kib, d.split_cnt_n = split_ws.numel() * 4 // 1024, split_cnt.numel()
-                d.tile = _lib.TILE_WINO4 | _lib.tile_w4_ksplit(S) | (0x1000000 if old else 0)
+                d.tile = _lib.TILE_WINO4 | _lib.tile_w4_ksplit(S)
             else:
                 d.tile = {'wino': 0, 'wino1': 0x4000, 'wino2': 0x8000, 'winochunk': 0x20000,
-                          'wino4': _lib.TILE_WINO4, 'wino4old': _lib.TILE_WINO4 | 0x1000000}[tile] if tile.startswith('wino') else _lib.TILES[tile]
+                          'wino4': _lib.TILE_WINO4}[tile] if tile.startswith('wino') else _lib.TILES[tile]
             d.dtype = {'f32': _lib.DTYPE_F32, 'bf16': _lib.DTYPE_BF16, 'f32x6': _lib.DTYPE_F32X6}[args.dtype]
             rc = 0
             for _ in range(2):
