@@ -154,7 +154,7 @@ int shapy_conv2d(const ShapyConv *desc_host, void *stream);
  * x[i] = self.branches[i](x[i])`).  Every descriptor must be one that shapy_conv2d would run on
  * the F(4x4) kernel (float32, SHAPY_TILE_WINO4 set, wgt_wino given, Cin % 16 == 0, Cout % 48 == 0,
  * tensors within 1 GiB); otherwise SHAPY_EINVAL and nothing is launched -- call shapy_conv2d per
- * layer instead.  No descriptor may read what another one writes.  Results are bit-identical to n
+ * layer instead.  No descriptor may read what another one writes.  Results equal those of n
  * shapy_conv2d calls. */
 int shapy_conv2d_group(const ShapyConv *descs_host, int n, void *stream);
 

@@ -39,10 +39,16 @@ namespace shapy {
 // last wave unit to arrive adds them IN SLICE ORDER and runs the epilogue -- the protocol of the F(4x4) kernel
 // (conv_wino4.h: Wino4Split), for the K-deep layers on small maps that stay on this kernel: every 3x3 conv in
 // bf16 storage, the head's 1x1 GEMMs and the stride-2 fuse convs at small batches.
+// P11: a plain GEMM (1x1 / stride 1 / pad 0: the head's wide layers, every fuse / transition 1x1): no taps, no
+// image borders -- the per-chunk address arithmetic (tap offsets, two border compares and a select per staged
+// row) disappears: fixed per-lane offsets, the chunk in the scalar offset of the buffer load.  On gfx950 a VALU
+// instruction between the f32 MFMAs of a wave is not hidden (tools/mfma_fillers.hip): ~9 of them per 16-MFMA
+// chunk on the 32 x 64 tile.
 template <typename T, int BM, int BN, int WM, int WN, int UPS, int KQ, int PD = 1, bool FLAT = false,
-          bool SPLIT = false>
+          bool SPLIT = false, bool P11 = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   static_assert(!SPLIT || (UPS == 1 && !FLAT), "split-K: plain epilogue, per-tap K chunks");
+  static_assert(!P11 || (PD == 1 && !FLAT), "plain-GEMM form: one chunk in flight, per-tap K chunks");
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(KQ == 4 || KQ == 8, "16-byte slots per staged row");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -100,6 +106,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     a_off[i] = ((b * p.Hi + hi0) * p.Wi + wi0) * p.in_ld * ESZ + (FLAT ? 0 : kq * 16);
     a_h[i] = m < p.M ? hi0 : -0x40000000;
     a_w[i] = wi0;
+    if constexpr (P11) a_off[i] = m < p.M ? a_off[i] : OOB;      // the only validity a plain GEMM row has
   }
   const int Kw = p.ks * p.ks * p.Cin;
   int b_off[BR];
@@ -128,6 +135,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   int left = n_chunks;                         // chunks still to be fetched: later requests read zeros
 
   auto gload = [&](int set) {
+    if constexpr (P11) {
+      // (only live chunks are requested on the PD = 1 path; rows beyond M / Cout carry an out-of-range offset)
+      const int so = c0 * ESZ;
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        a_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_off[i], so, 0);
+#pragma unroll
+      for (int i = 0; i < BR; ++i)
+        b_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i], so, 0);
+      c0 += BK;
+      --left;
+      return;
+    }
     const int tap_in = ((kh * p.Wi + kw) * p.in_ld + c0) * ESZ;
     const int tap_w = FLAT ? kflat * ESZ : ((kh * p.ks + kw) * p.Cin + c0) * ESZ;
     // (kh < ks: the flat-K kernel's LAST chunk may reach past the K extent in some of its slots)
@@ -370,6 +390,13 @@ static int launch(ConvK k, hipStream_t s) {
       return SHAPY_EINVAL;
     }
   }
+  if constexpr (sizeof(typename T::elem) == 4 && UPS == 1 && KQ == 8 && BM <= 64 && BN <= 64) {
+    if (k.ks == 1 && k.stride == 1 && k.pad == 0 && !k.pd3 && !k.no_p11) {
+      hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, 1, KQ, 1, false, false, true>), dim3(nwg), dim3(256),
+                         0, s, k);
+      return (int)hipGetLastError();
+    }
+  }
   if (UPS == 1 && k.pd3)
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, 1, KQ, 3>), dim3(nwg), dim3(256), 0, s, k);
   else
@@ -487,6 +514,7 @@ int conv_prepare(const ShapyConv &d, ConvK &k, int *empty) {
   k.swz = (d.tile & 0x400) ? 0 : 1;
   k.no_nslab = (d.tile & 0x10000) ? 1 : 0;
   k.no_allk = (d.tile & 0x20000) ? 1 : 0;
+  k.no_p11 = (d.tile & 0x1000000) ? 1 : 0;
   // F(4x4) split-K (conv_wino4.hip): SHAPY_TILE_W4_KSPLIT(S) in the tile word, slab + counters from
   // the caller
   k.ups_split = 1;

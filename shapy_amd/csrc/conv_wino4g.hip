@@ -13,7 +13,8 @@
 // SIMDs per CU that multiply).  Here
 //   * a TASK is what a workgroup of conv_wino4.hip does: 16 tiles x 48 output channels x all of K
 //     of ONE of the group's convolutions; the arithmetic, lane maps, LDS image and filter layout
-//     are exactly conv_wino4.hip's, so results are bit-identical to the per-layer launches;
+//     are exactly conv_wino4.hip's, so results equal the per-layer launches' to float32 rounding (that kernel's fourth wave adds
+//     Winograd rows 4 / 5 in another association since round 6);
 //   * the grid is 2 workgroups per CU = 64 slots per XCD.  XCD x owns a contiguous run of every
 //     convolution's n-major task list (a filter slab stays in ITS L2); inside an XCD the tasks are
 //     dealt to the slots by a longest-processing-time schedule that the HOST computes per launch

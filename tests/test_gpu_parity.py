@@ -721,10 +721,12 @@ def test_hrnet_graph_replay_equals_eager(network, multi_stream):
 def test_hrnet_grouped_branch_launches_equal_per_layer_launches(network, B, size, multi_stream, graph):
     """group_branches (the default): the convs at one depth of a module's parallel branches run as
     ONE persistent F(4x4) launch (csrc/conv_wino4g.hip, through shapy_hrnet_run's `group` ops)
-    instead of one conv_wino4 launch per branch and stream -- same tasks, same arithmetic:
-    bit-identical features, at the headline batch too, eager and as a captured hipGraph.  (Per-layer
-    launches WITHOUT split-K: the persistent kernel has no split form, and a split layer adds its
-    partial sums in another association -- compared to rounding below.)"""
+    instead of one conv_wino4 launch per branch and stream -- same tasks, same products; deterministic
+    from call to call, at the headline batch too, eager and as a captured hipGraph.  Against the per-layer
+    kernel the features agree to float32 rounding: since round 6 the per-layer kernel adds Winograd rows 4 / 5
+    of a tile in another association (its fourth wave's partial x-transform, csrc/conv_wino4.hip), as a
+    split layer adds its slices' partial sums in another one -- both compared to rounding below.  (Per-layer
+    launches WITHOUT split-K are the reference: the persistent kernel has no split form.)"""
     from shapy_amd.utils import synthetic as syn
     bb = network.backbone
     keep = bb.group_branches, bb.multi_stream, bb.use_graph, bb.conv_algo, bb.wino4_min_hw
@@ -751,7 +753,8 @@ def test_hrnet_grouped_branch_launches_equal_per_layer_launches(network, B, size
     finally:
         bb.group_branches, bb.multi_stream, bb.use_graph, bb.conv_algo, bb.wino4_min_hw = keep
         bb.wino4_ksplit = keep_split
-    assert torch.equal(got, ref) and torch.equal(again, ref)
+    assert torch.equal(again, got)
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
     assert (split - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
     if size == 224:
         assert not torch.equal(split, ref)               # the split layers really ran
@@ -1051,7 +1054,7 @@ def test_hrnet_head_gemms_on_bf16x6_vs_f32_kernel(network):
             small = bb(x[:8])['concat'].clone()            # a smaller batch keeps the f32 kernel ...
             bb.x6_gemm_min_batch = 0
             assert torch.equal(small, bb(x[:8])['concat'])  # ... bit for bit
-        plans = [e['plan'] for k, e in bb._engine.items() if k[0] == 224 and k[13] is True]
+        plans = [e['plan'] for k, e in bb._engine.items() if k[0] == 224 and k[12] is True]
         assert plans and sum(1 for o in plans[-1].ops if o['tile'] & _lib.TILE_X6) == 15
     finally:
         bb.multi_stream, bb.x6_gemm_min_batch = keep

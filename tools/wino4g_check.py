@@ -1,5 +1,7 @@
 """Canary + parity + timing of the persistent grouped F(4x4) launch (csrc/conv_wino4g.hip) against
-one shapy_conv2d (conv_wino4.hip) per layer: results must be bit-identical.
+one shapy_conv2d (conv_wino4.hip) per layer: same tasks, same products; NaN pattern (untouched channels of a
+concat epilogue) identical, values equal to float32 rounding (since round 6 the per-layer kernel adds the Winograd
+rows 4 / 5 of a tile in another association: its fourth wave's partial x-transform).
 
     timeout 120 python tools/wino4g_check.py --canary      # tiny cases first (a protocol bug hangs)
     python tools/wino4g_check.py --bench                   # HRNet level groups at B = 64
@@ -64,10 +66,12 @@ def run_case(lib, shapes, seed, stream):
     ok = True
     for i, (k, ref) in enumerate(zip(keep, refs)):
         got = k['out']
-        same = torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(ref, nan=-7.0))
+        g0, r0 = torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(ref, nan=-7.0)
+        tol = 2e-5 * max(1.0, float(r0.abs().max()))
+        same = bool(torch.equal(torch.isnan(got), torch.isnan(ref)) and float((g0 - r0).abs().max()) <= tol)
         ok &= same
         if not same:
-            bad = (torch.nan_to_num(got, nan=-7.0) != torch.nan_to_num(ref, nan=-7.0))
+            bad = (g0 - r0).abs() > tol
             print('   MISMATCH conv', i, shapes[i], 'elements', int(bad.sum()), 'of', bad.numel(),
                   'first', bad.nonzero()[:3].tolist())
     print(('ok  ' if ok else 'FAIL'), shapes)
