@@ -47,7 +47,6 @@ struct ConvK {
   int flat;                     // bf16, Cin % 32 != 0: flat-K kernel
   int pd3;                      // implicit GEMM: three chunks of global loads in flight
   int ups_split;                // upsample-scatter layers: workgroups per tile, each scatters ups / ups_split rows
-  int no_p11;                   // A/B knob (tile flag 0x1000000): 1x1 layers on the generic per-tap loop
   int ksplit;                   // K slices per output tile (SHAPY_TILE_KSPLIT), 1 = none: F(4x4) and implicit GEMM
   void *split_ws;               // ... their slab (ShapyConv.split_ws), the bytes the launch uses of it ...
   unsigned split_bytes;

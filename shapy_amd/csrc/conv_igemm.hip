@@ -39,16 +39,17 @@ namespace shapy {
 // last wave unit to arrive adds them IN SLICE ORDER and runs the epilogue -- the protocol of the F(4x4) kernel
 // (conv_wino4.h: Wino4Split), for the K-deep layers on small maps that stay on this kernel: every 3x3 conv in
 // bf16 storage, the head's 1x1 GEMMs and the stride-2 fuse convs at small batches.
-// P11: a plain GEMM (1x1 / stride 1 / pad 0: the head's wide layers, every fuse / transition 1x1): no taps, no
-// image borders -- the per-chunk address arithmetic (tap offsets, two border compares and a select per staged
-// row) disappears: fixed per-lane offsets, the chunk in the scalar offset of the buffer load.  On gfx950 a VALU
-// instruction between the f32 MFMAs of a wave is not hidden (tools/mfma_fillers.hip): ~9 of them per 16-MFMA
-// chunk on the 32 x 64 tile.
+// PD = 1 (every float32 layer): the address arithmetic of a staged row -- tap offset, two image-border compares,
+// a select -- is done once per filter TAP, not per chunk: per-lane offsets of the current tap in registers, the
+// channel chunk in the scalar offset of the buffer load (a 1x1 layer computes them once).  On gfx950 a VALU
+// instruction between the f32 MFMAs of a wave is not hidden (tools/mfma_fillers.hip: they share the FMA lanes);
+// the per-chunk form spent ~9 of them per 16-MFMA chunk on the 32 x 64 tile: the head's 2048 -> 2048 GEMM 238 ->
+// 212 us (124 TFLOP/s), end to end +1.1 % (profiles/r06j_plain_gemm_ab.txt).
 template <typename T, int BM, int BN, int WM, int WN, int UPS, int KQ, int PD = 1, bool FLAT = false,
-          bool SPLIT = false, bool P11 = false>
+          bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   static_assert(!SPLIT || (UPS == 1 && !FLAT), "split-K: plain epilogue, per-tap K chunks");
-  static_assert(!P11 || (PD == 1 && !FLAT), "plain-GEMM form: one chunk in flight, per-tap K chunks");
+  constexpr bool TAPH = PD == 1 && !FLAT;      // per-tap address arithmetic (only live chunks are requested there)
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(KQ == 4 || KQ == 8, "16-byte slots per staged row");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -106,7 +107,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     a_off[i] = ((b * p.Hi + hi0) * p.Wi + wi0) * p.in_ld * ESZ + (FLAT ? 0 : kq * 16);
     a_h[i] = m < p.M ? hi0 : -0x40000000;
     a_w[i] = wi0;
-    if constexpr (P11) a_off[i] = m < p.M ? a_off[i] : OOB;      // the only validity a plain GEMM row has
   }
   const int Kw = p.ks * p.ks * p.Cin;
   int b_off[BR];
@@ -134,18 +134,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   }
   int left = n_chunks;                         // chunks still to be fetched: later requests read zeros
 
+  // TAPH: byte offsets of this thread's staged rows for the CURRENT tap (out-of-image / beyond M or Cout: OOB)
+  int a_vo[AR], b_vo[BR];
+  auto set_tap = [&]() {
+    const int tap_in = (kh * p.Wi + kw) * p.in_ld * ESZ, tap_w = (kh * p.ks + kw) * p.Cin * ESZ;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const bool ok = (unsigned)(a_h[i] + kh) < (unsigned)p.Hi && (unsigned)(a_w[i] + kw) < (unsigned)p.Wi;
+      a_vo[i] = ok ? a_off[i] + tap_in : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) b_vo[i] = b_off[i] == OOB ? OOB : b_off[i] + tap_w;
+  };
+  if constexpr (TAPH) set_tap();
   auto gload = [&](int set) {
-    if constexpr (P11) {
-      // (only live chunks are requested on the PD = 1 path; rows beyond M / Cout carry an out-of-range offset)
+    if constexpr (TAPH) {
       const int so = c0 * ESZ;
 #pragma unroll
       for (int i = 0; i < AR; ++i)
-        a_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_off[i], so, 0);
+        a_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_vo[i], so, 0);
 #pragma unroll
       for (int i = 0; i < BR; ++i)
-        b_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i], so, 0);
+        b_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_vo[i], so, 0);
       c0 += BK;
       --left;
+      if (c0 == p.Cin) {                         // next tap (uniform branch)
+        c0 = 0;
+        if (++kw == p.ks) { kw = 0; ++kh; }
+        set_tap();
+      }
       return;
     }
     const int tap_in = ((kh * p.Wi + kw) * p.in_ld + c0) * ESZ;
@@ -390,13 +407,6 @@ static int launch(ConvK k, hipStream_t s) {
       return SHAPY_EINVAL;
     }
   }
-  if constexpr (sizeof(typename T::elem) == 4 && UPS == 1 && KQ == 8 && BM <= 64 && BN <= 64) {
-    if (k.ks == 1 && k.stride == 1 && k.pad == 0 && !k.pd3 && !k.no_p11) {
-      hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, 1, KQ, 1, false, false, true>), dim3(nwg), dim3(256),
-                         0, s, k);
-      return (int)hipGetLastError();
-    }
-  }
   if (UPS == 1 && k.pd3)
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, 1, KQ, 3>), dim3(nwg), dim3(256), 0, s, k);
   else
@@ -514,7 +524,6 @@ int conv_prepare(const ShapyConv &d, ConvK &k, int *empty) {
   k.swz = (d.tile & 0x400) ? 0 : 1;
   k.no_nslab = (d.tile & 0x10000) ? 1 : 0;
   k.no_allk = (d.tile & 0x20000) ? 1 : 0;
-  k.no_p11 = (d.tile & 0x1000000) ? 1 : 0;
   // F(4x4) split-K (conv_wino4.hip): SHAPY_TILE_W4_KSPLIT(S) in the tile word, slab + counters from
   // the caller
   k.ups_split = 1;

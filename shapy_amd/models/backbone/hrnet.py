@@ -231,7 +231,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self._engine = {}
         self.multi_stream = True
         self.tile_overrides = {}
-        self.tile_flags = 0          # OR-ed into every conv's tile id (tuning knobs)
+        self.tile_flags = int(os.environ.get('SHAPY_TILE_FLAGS', '0'), 0)   # OR-ed into every conv's tile id (tuning knobs)
         #: replay the forward as one hipGraph (csrc/capi.hip): True (the captured barrier plan), False, or 'auto' =
         #: True for batches up to graph_max_batch = 0, i.e. never: the eager event-driven forward is faster than the
         #: replay at every batch size (B = 1: 5.5 vs 6.3 ms, B = 64: 12.8 vs 14.0)
