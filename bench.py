@@ -182,8 +182,8 @@ def cpu_model():
 def cpu_baseline_and_parity(x_np, out, size):
     """CPU oracle on the LAST timed batch (rank 0, after the timed region): its wall time is the
     all-cores CPU baseline at the headline batch size, its result is the parity reference.
-    SURVEY.md 8(d): warm-up 1, median of 3 full batches by default (a bounded sample: ~15 s of host time;
-    SHAPY_CPU_BASELINE_REPS=5 for the survey's median of 5), time.perf_counter, same inputs / weights, at the
+    SURVEY.md 8(d): warm-up 1, median of 5 full batches (a bounded sample: ~25 s of host time on the GPU box's
+    64 cores; SHAPY_CPU_BASELINE_REPS overrides), time.perf_counter, same inputs / weights, at the
     headline batch AND at bs = 4, all cores and ONE thread (the reference pins its pools to one
     thread, demo.py:432)."""
     import numpy as np
@@ -193,7 +193,7 @@ def cpu_baseline_and_parity(x_np, out, size):
     cores = min(torch.get_num_threads(), 64)      # more threads only add scheduling noise here
     torch.set_num_threads(cores)
     n = x_np.shape[0]
-    reps = int(os.environ.get('SHAPY_CPU_BASELINE_REPS', '3'))
+    reps = int(os.environ.get('SHAPY_CPU_BASELINE_REPS', '5'))
 
     def timed(xs, k):
         ts, last = [], None

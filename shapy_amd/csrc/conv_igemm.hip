@@ -39,8 +39,8 @@ namespace shapy {
 // last wave unit to arrive adds them IN SLICE ORDER and runs the epilogue -- the protocol of the F(4x4) kernel
 // (conv_wino4.h: Wino4Split), for the K-deep layers on small maps that stay on this kernel: every 3x3 conv in
 // bf16 storage, the head's 1x1 GEMMs and the stride-2 fuse convs at small batches.
-// PD = 1 (every float32 layer): the address arithmetic of a staged row -- tap offset, two image-border compares,
-// a select -- is done once per filter TAP, not per chunk: per-lane offsets of the current tap in registers, the
+// Unless FLAT: the address arithmetic of a staged row -- tap offset, two image-border compares, a select -- is
+// done once per filter TAP, not per chunk: per-lane offsets of the current tap in registers, the
 // channel chunk in the scalar offset of the buffer load (a 1x1 layer computes them once).  On gfx950 a VALU
 // instruction between the f32 MFMAs of a wave is not hidden (tools/mfma_fillers.hip: they share the FMA lanes);
 // the per-chunk form spent ~9 of them per 16-MFMA chunk on the 32 x 64 tile: the head's 2048 -> 2048 GEMM 238 ->
@@ -49,7 +49,7 @@ template <typename T, int BM, int BN, int WM, int WN, int UPS, int KQ, int PD = 
           bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   static_assert(!SPLIT || (UPS == 1 && !FLAT), "split-K: plain epilogue, per-tap K chunks");
-  constexpr bool TAPH = PD == 1 && !FLAT;      // per-tap address arithmetic (only live chunks are requested there)
+  constexpr bool TAPH = !FLAT;                 // per-tap address arithmetic (flat K: a chunk's slots may straddle taps)
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(KQ == 4 || KQ == 8, "16-byte slots per staged row");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -138,24 +138,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   int a_vo[AR], b_vo[BR];
   auto set_tap = [&]() {
     const int tap_in = (kh * p.Wi + kw) * p.in_ld * ESZ, tap_w = (kh * p.ks + kw) * p.Cin * ESZ;
+    const bool tap_ok = kh < p.ks;               // (PD > 1 runs past the last tap)
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const bool ok = (unsigned)(a_h[i] + kh) < (unsigned)p.Hi && (unsigned)(a_w[i] + kw) < (unsigned)p.Wi;
-      a_vo[i] = ok ? a_off[i] + tap_in : OOB;
+      a_vo[i] = (ok && tap_ok) ? a_off[i] + tap_in : OOB;
     }
 #pragma unroll
-    for (int i = 0; i < BR; ++i) b_vo[i] = b_off[i] == OOB ? OOB : b_off[i] + tap_w;
+    for (int i = 0; i < BR; ++i) b_vo[i] = (b_off[i] == OOB || !tap_ok) ? OOB : b_off[i] + tap_w;
   };
   if constexpr (TAPH) set_tap();
   auto gload = [&](int set) {
     if constexpr (TAPH) {
       const int so = c0 * ESZ;
+      // PD > 1 keeps requesting chunks past the last one (no branch around a load: exact vmcnt counts); those
+      // read zeros: beyond the last tap set_tap() has marked every row out of range, inside a split-K slice's
+      // neighbour the uniform `left` decides
+      const bool live = PD == 1 || left > 0;
 #pragma unroll
       for (int i = 0; i < AR; ++i)
-        a_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_vo[i], so, 0);
+        a_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, live ? a_vo[i] : OOB, so, 0);
 #pragma unroll
       for (int i = 0; i < BR; ++i)
-        b_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_vo[i], so, 0);
+        b_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, live ? b_vo[i] : OOB, so, 0);
       c0 += BK;
       --left;
       if (c0 == p.Cin) {                         // next tap (uniform branch)
