@@ -288,6 +288,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: faster configuration at every batch size measured (B = 64: 4,745 vs 4,662 images/s; one
         #: stream: 14.1 vs 16.3 ms per step in favour of the groups; profiles/r03m_*)
         self.group_branches = {'1': True, '0': False}.get(os.environ.get('SHAPY_GROUP_BRANCHES', ''), 'auto')
+        #: order of the terms of a fuse output (SHAPY_FUSE_NEAR_FIRST=0: ascending branch index as in rounds 1-5)
+        self.fuse_near_first = os.environ.get('SHAPY_FUSE_NEAR_FIRST', '1') != '0'
         #: multi-stream plans: explicit dependencies (events) instead of a join between the branches
         #: and the fuse layers of a module (False: the round-2 barrier plan)
         self.dag = True
@@ -687,6 +689,13 @@ class HighResolutionNet(VersionedWeights, nn.Module):
             for i in range(len(m.fuse_layers)):
                 xi, Hi_, Wi_ = ys[i]
                 terms = [j for j in range(nb) if j != i]
+                if self.fuse_near_first:
+                    # stride-2 terms from the NEAREST branch first: its input is that branch's own output (ready when
+                    # the branch ends, no leading convs) and its conv is the widest (192 -> 384 at 14x14: 4.2 GFLOP);
+                    # the chain from branch 0 arrives last and ends in the narrowest conv.  In ascending order the wide
+                    # conv ran last on the lane that then starts the next module's 7x7 branch 340-430 us late
+                    # (profiles/r06g_module_tails.txt).  Same terms, another summation order (float32 rounding).
+                    terms = [j for j in range(i - 1, -1, -1)] + [j for j in range(i + 1, nb)]
                 use_last = last_out is not None and i == nb - 1
                 outb = last_out[0] if use_last else P.buf(Hi_, Wi_, xi.C)
                 o_ld = last_out[1] if use_last else xi.C
@@ -792,7 +801,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
                  tuple(sorted(self.layer_algo.items())), self.tile_flags,
                  tuple(sorted(self.tile_overrides.items())))
         lx6 = self.compute_dtype == 'f32' and 0 < self.x6_gemm_min_batch <= (B or 0)
-        key_w += (lx6,)
+        key_w += (lx6, self.fuse_near_first)
         key = key_w + (tuple(sorted(pol.items())) + tuple(sorted(dpol.items())),)
         eng = self._engine.get(key)
         if eng is not None:
