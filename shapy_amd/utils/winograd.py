@@ -15,7 +15,7 @@ AT = np.array([[1.0, 1, 1, 0], [0, 1, -1, -1]])
 
 def eligible(ksize, stride, pad, cin, cout, ups=1):
     """Layers conv_wino.hip takes (ShapyConv.wgt_wino): 3x3 / stride 1 / pad 1, 16-channel
-    K chunks, 48- or 64-channel N tiles."""
+    K chunks, 48- or 64-channel N tiles (F(2x2): conv_wino.hip)."""
     return (ksize == 3 and stride == 1 and pad == 1 and ups == 1 and cin % 16 == 0
             and (cout % 48 == 0 or cout % 64 == 0))
 

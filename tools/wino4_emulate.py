@@ -1,5 +1,7 @@
-"""Thread-by-thread NumPy emulation of one conv_wino4_kernel workgroup (csrc/conv_wino4.hip): the
-staging wave's lane map and byte offsets (incl. the 0x40000000 "out of range" arithmetic of the
+"""Thread-by-thread NumPy emulation of one F(4x4) workgroup in its one-staging-wave + three-multiplying-waves
+form (rounds 2-5's conv_wino4.hip; since round 6 the form of the grouped persistent kernel csrc/conv_wino4g.hip
+only -- the per-layer kernel lets all four waves multiply and stage, same LDS image, same fragment and filter
+addressing, same epilogue): the staging wave's lane map and byte offsets (incl. the 0x40000000 "out of range" arithmetic of the
 buffer loads), the XOR-swizzled LDS image, the multiplying waves' fragment addressing, the MFMA
 16x16x4 operand / result lane layout with the "4 consecutive k per lane" trick, the filter-ring
 addresses, the in-register output transform (one tile x four channels per lane) and the scalar-offset
@@ -243,6 +245,6 @@ if __name__ == '__main__':
     check(2, 12, 20, 48, 48, True, True)                # 30 tiles: two workgroups, 3 chunks
     check(1, 7, 9, 32, 96, True, False)                 # partial edge tiles, two N tiles
     check(1, 14, 14, 16, 48, False, False, coff=16)     # concat-style channel offset
-    check(1, 9, 10, 32, 64, True, True)                 # 64-channel N tile: four multiplying waves
+    check(1, 9, 10, 32, 64, True, True)                 # (the 64-channel N tile of rounds 4-5: four multiplying waves)
     check(1, 6, 6, 16, 128, False, True)                # ... two of them
     print('emulation OK')
