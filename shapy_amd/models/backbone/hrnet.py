@@ -231,7 +231,7 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         self._engine = {}
         self.multi_stream = True
         self.tile_overrides = {}
-        self.tile_flags = int(os.environ.get('SHAPY_TILE_FLAGS', '0'), 0)   # OR-ed into every conv's tile id (tuning knobs)
+        self.tile_flags = 0          # OR-ed into every conv's tile id (tuning knobs)
         #: replay the forward as one hipGraph (csrc/capi.hip): True (the captured barrier plan), False, or 'auto' =
         #: True for batches up to graph_max_batch = 0, i.e. never: the eager event-driven forward is faster than the
         #: replay at every batch size (B = 1: 5.5 vs 6.3 ms, B = 64: 12.8 vs 14.0)
@@ -288,8 +288,8 @@ class HighResolutionNet(VersionedWeights, nn.Module):
         #: faster configuration at every batch size measured (B = 64: 4,745 vs 4,662 images/s; one
         #: stream: 14.1 vs 16.3 ms per step in favour of the groups; profiles/r03m_*)
         self.group_branches = {'1': True, '0': False}.get(os.environ.get('SHAPY_GROUP_BRANCHES', ''), 'auto')
-        #: order of the terms of a fuse output (SHAPY_FUSE_NEAR_FIRST=0: ascending branch index as in rounds 1-5)
-        self.fuse_near_first = os.environ.get('SHAPY_FUSE_NEAR_FIRST', '1') != '0'
+        #: order of the terms of a fuse output (False: ascending branch index as in rounds 1-5)
+        self.fuse_near_first = True
         #: multi-stream plans: explicit dependencies (events) instead of a join between the branches
         #: and the fuse layers of a module (False: the round-2 barrier plan)
         self.dag = True

@@ -433,6 +433,9 @@ def test_winograd4_plan_filters_and_kernel_indexing(hrnet):
     emu.check(2, 12, 20, 48, 48, True, True)             # two workgroups, 3 chunks, residual
     emu.check(1, 7, 9, 32, 96, True, False)              # partial edge tiles, two N tiles
     emu.check(1, 14, 14, 16, 48, False, False, coff=16)  # channel-offset epilogue
+    # the per-layer kernel's four-multiplying-wave workgroup (round 6): staging by all waves, 27-item split, exchange
+    emu.check(2, 12, 20, 48, 48, True, True, four_waves=True)
+    emu.check(1, 7, 9, 32, 96, True, False, four_waves=True)
 
 
 def test_split_k_policy_marks_the_7x7_branch_and_nothing_else(hrnet):

@@ -6,8 +6,9 @@ buffer loads), the XOR-swizzled LDS image, the multiplying waves' fragment addre
 16x16x4 operand / result lane layout with the "4 consecutive k per lane" trick, the filter-ring
 addresses, the in-register output transform (one tile x four channels per lane) and the scalar-offset
 16-byte residual / store addressing --
-everything except the hardware semantics themselves.  Compares every workgroup's output with a
-float64 direct convolution.  CPU only:
+everything except the hardware semantics themselves -- and `emulate_workgroup4`, the same for the per-layer
+kernel's four-multiplying-wave workgroup (staging lane map of all four waves, row-pair transform, 27-item split,
+wave 3's exchange).  Compares every workgroup's output with a float64 direct convolution.  CPU only:
 
     python tools/wino4_emulate.py              # kernel indexing, several shapes
     python tools/wino4_emulate.py --network    # F(4x4,3x3) float32 numerics through all of HRNet-W48
@@ -151,6 +152,132 @@ def emulate_workgroup(x, u, bias, res, relu, out, wg_m, wg_n, out_ld, out_coff, 
                         outf[oo // 4: oo // 4 + 4] = v
 
 
+def emulate_workgroup4(x, u, bias, res, relu, out, wg_m, wg_n, out_ld, out_coff, res_ld, res_coff):
+    """The FOUR-multiplying-wave workgroup of csrc/conv_wino4.hip (round 6): staging by every wave (lane = tile 4 w +
+    (l >> 4), channel l & 15, dword loads, row-pair layout, x pass on pairs, y pass per column), the same LDS image
+    and fragment reads, the 27-item split (waves 0-2: positions 0..26 of their 16 channels; wave 3: positions
+    27..35 of all three channel groups), wave 3's partial x transform through the exchange buffer, the owners'
+    completion of rows 4 / 5, then the shared epilogue."""
+    B, H, W, in_ld = x.shape
+    Cin = in_ld
+    Cout = u.shape[2]
+    TW, TH = (W + 3) // 4, (H + 3) // 4
+    T = B * TH * TW
+    CC = Cin // 16
+    m_blk, n_blk = wg_m * 16, wg_n * 48
+    xin = x.reshape(-1)
+    in_bytes = xin.size * 4
+    uflat = u.reshape(-1)
+    u_bytes = uflat.size * 4
+    lds = np.zeros(2 * LDS_V // 4, f32)
+    acc = np.zeros((4, 64, 27, 4), np.float64)          # wave, lane, item, r
+    pix_stride = in_ld * 4
+    u_pos, u_chunk = CC * Cout * 64, Cout * 64
+    for cc in range(CC):
+        # ---- staging, all four waves: one channel of one tile per lane ----
+        for wave in range(4):
+            for lane in range(64):
+                tile_s, ch = 4 * wave + (lane >> 4), lane & 15
+                tile = m_blk + tile_s
+                live = tile < T
+                tt = tile if live else 0
+                tx, tq = tt % TW, tt // TW
+                ty, b = tq % TH, tq // TH
+                y0, x0 = 4 * ty - 1, 4 * tx - 1
+                row_off = [((b * H + y0 + i) * W * pix_stride + ch * 4) if (live and 0 <= y0 + i < H)
+                           else BAD for i in range(6)]
+                col_off = [(x0 + j) * pix_stride if 0 <= x0 + j < W else BAD for j in range(6)]
+                # (the chunk sits in the buffer load's SCALAR offset, which the bounds check does not see)
+                d = [[xin[(row_off[i] + col_off[j] + cc * 64) // 4] if row_off[i] + col_off[j] < in_bytes else f32(0)
+                      for j in range(6)] for i in range(6)]
+                # row pairs rp[k][j] = (d[2k][j], d[2k+1][j]); x pass on whole pairs
+                rp = [[np.array([d[2 * k][j], d[2 * k + 1][j]], f32) for j in range(6)] for k in range(3)]
+                for k in range(3):
+                    rp[k] = bt6(rp[k])
+                st_off = tile_s * 64 + ((((ch >> 2) ^ tile_s ^ (tile_s >> 1)) & 3) << 4) + (ch & 3) * 4
+                for j in range(6):
+                    P0, P1, P2 = rp[0][j], rp[1][j], rp[2][j]
+                    o05 = f32(4) * P0 + (f32(-5) * P1 + P2)                   # (o0, o5)
+                    U_, W_ = f32(-4) * P1 + P2, f32(-4) * P0 + P1             # a = U.lo, b = W.hi
+                    C_, E_ = P2 - P1, P1 - P0                                 # c = C.lo, e = E.hi
+                    o12 = np.array([U_[0] + W_[1], U_[0] - W_[1]], f32)       # op_sel (lo, hi), neg_hi
+                    o34 = np.array([E_[1] * f32(2) + C_[0], -E_[1] * f32(2) + C_[0]], f32)
+                    v = [o05[0], o12[0], o12[1], o34[0], o34[1], o05[1]]
+                    for i in range(6):
+                        lds[((cc & 1) * LDS_V + st_off + (6 * i + j) * PSTR) // 4] = v[i]
+        # ---- multiplying: 27 items per wave ----
+        for wave in range(4):
+            w3 = wave == 3
+            AF = np.zeros((27, 64, 4), f32)
+            BF = np.zeros((27, 64, 4), f32)
+            for lane in range(64):
+                g, l15 = lane >> 4, lane & 15
+                frag_off = l15 * 64 + (((g ^ l15 ^ (l15 >> 1)) & 3) << 4)
+                u_lane = ((n_blk + 16 * (0 if w3 else wave) + l15) * 16 + 4 * g) * 4
+                for q in range(27):
+                    pos = 27 + q // 3 if w3 else q
+                    o = ((cc & 1) * LDS_V + frag_off + pos * PSTR) // 4
+                    AF[q, lane] = lds[o:o + 4]
+                    BF[q, lane] = buf_load(uflat, u_bytes,
+                                           u_lane + pos * u_pos + cc * u_chunk + ((q % 3) * 1024 if w3 else 0), 16)
+            A = BF.reshape(27, 4, 16, 4).astype(np.float64)            # q, g, i (channel), kk
+            Bm = AF.reshape(27, 4, 16, 4).astype(np.float64)           # q, g, j (tile), kk
+            D = np.einsum('qgik,qgjk->qij', A, Bm)
+            for lane in range(64):
+                g, l15 = lane >> 4, lane & 15
+                for r in range(4):
+                    acc[wave, lane, :, r] += D[:, 4 * g + r, l15]
+    # ---- wave 3: x transform of what it holds -> exchange buffer X[n][k][lane] ----
+    X = np.zeros((3, 8, 64, 4), f32)
+    for lane in range(64):
+        a3 = acc[3, lane].astype(f32)                                  # item 3 k + n, k = position - 27
+        for n in range(3):
+            m3, m4, m5 = a3[0 + n], a3[3 + n], a3[6 + n]               # M[4][3..5]
+            s34, d34 = m3 + m4, m3 - m4
+            X[n, 0, lane], X[n, 1, lane], X[n, 2, lane] = s34, f32(2) * d34, f32(4) * s34
+            X[n, 3, lane] = f32(8) * d34 + m5
+            row5 = at6([a3[9 + n], a3[12 + n], a3[15 + n], a3[18 + n], a3[21 + n], a3[24 + n]])
+            for k in range(4):
+                X[n, 4 + k, lane] = row5[k]
+    # ---- owners: rows 0..3 from their own accumulators, row 4 = own half + wave 3's, row 5 = wave 3's ----
+    outf = out.reshape(-1)
+    for wave in range(3):
+        n0 = n_blk + 16 * wave
+        for lane in range(64):
+            g, l15 = lane >> 4, lane & 15
+            col4 = n0 + 4 * g
+            tile = m_blk + l15
+            live = tile < T
+            tt = tile if live else 0
+            tx, tq = tt % TW, tt // TW
+            ty, b = tq % TH, tq // TH
+            pix0 = (b * H + 4 * ty) * W + 4 * tx
+            obase = (pix0 * out_ld + out_coff + col4) * 4 if live else BAD
+            rbase = (pix0 * res_ld + res_coff + col4) * 4 if (live and res is not None) else BAD
+            nrow, ncol = H - 4 * ty, W - 4 * tx
+            m = acc[wave, lane].astype(f32)                            # item = position 0..26
+            s = [at6([m[6 * i + j] for j in range(6)]) for i in range(4)]
+            s12, d12 = m[25] + m[26], m[25] - m[26]
+            r = X[wave, :, lane]
+            s.append([(m[24] + s12) + r[0], d12 + r[1], s12 + r[2], d12 + r[3]])
+            s.append([r[4], r[5], r[6], r[7]])
+            for bb in range(4):
+                y = at6([s[i][bb] for i in range(6)])
+                for a in range(4):
+                    ok = a < nrow and bb < ncol
+                    rv = np.zeros(4, f32)
+                    if res is not None:
+                        ro = (rbase if ok else BAD) + (a * W + bb) * res_ld * 4
+                        rv = buf_load(res.reshape(-1), BAD, ro, 16) if ro < BAD else np.zeros(4, f32)
+                    v = (y[a] + bias[col4:col4 + 4]) + rv
+                    if relu:
+                        v = np.maximum(v, f32(0))
+                    oo = (obase if ok else BAD) + (a * W + bb) * out_ld * 4
+                    if oo < BAD:
+                        assert np.isnan(outf[oo // 4: oo // 4 + 4]).all(), 'element written twice'
+                        outf[oo // 4: oo // 4 + 4] = v
+
+
 def direct_conv(x, w, bias):
     B, H, W, C = x.shape
     xp = np.zeros((B, H + 2, W + 2, C))
@@ -162,7 +289,7 @@ def direct_conv(x, w, bias):
     return ref + bias
 
 
-def check(B, H, W, Cin, Cout, with_res, relu, coff=0, seed=0):
+def check(B, H, W, Cin, Cout, with_res, relu, coff=0, seed=0, four_waves=False):
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((B, H, W, Cin)).astype(f32)
     w = (rng.standard_normal((Cout, 3, 3, Cin)) / np.sqrt(9 * Cin)).astype(f32)
@@ -175,7 +302,7 @@ def check(B, H, W, Cin, Cout, with_res, relu, coff=0, seed=0):
     nby, nbx = (B * TH * TW + 15) // 16, Cout // (48 if Cout % 48 == 0 else 64)
     for m in range(nby):
         for n in range(nbx):
-            emulate_workgroup(
+            (emulate_workgroup4 if four_waves else emulate_workgroup)(
                 x, u, bias, res, relu, out, m, n, out_ld, coff, Cout, 0)
     ref = direct_conv(x, w, bias)
     if with_res:
@@ -186,7 +313,7 @@ def check(B, H, W, Cin, Cout, with_res, relu, coff=0, seed=0):
     assert not np.isnan(got).any(), 'unwritten outputs'
     assert coff == 0 or np.isnan(out[..., :coff]).all(), 'wrote outside its channel slice'
     err = np.abs(got - ref).max()
-    print(f'B={B} {H}x{W} {Cin}->{Cout} res={with_res} '
+    print(f'{"four-wave " if four_waves else ""}B={B} {H}x{W} {Cin}->{Cout} res={with_res} '
           f'relu={relu} coff={coff}: '
           f'{nby * nbx} workgroups, max err {err:.2e}')
     assert err < 2e-5, err
@@ -247,4 +374,9 @@ if __name__ == '__main__':
     check(1, 14, 14, 16, 48, False, False, coff=16)     # concat-style channel offset
     check(1, 9, 10, 32, 64, True, True)                 # (the 64-channel N tile of rounds 4-5: four multiplying waves)
     check(1, 6, 6, 16, 128, False, True)                # ... two of them
+    # the four-multiplying-wave workgroup of the per-layer kernel
+    check(1, 8, 8, 16, 48, False, True, four_waves=True)
+    check(2, 12, 20, 48, 48, True, True, four_waves=True)
+    check(1, 7, 9, 32, 96, True, False, four_waves=True)
+    check(1, 14, 14, 16, 48, False, False, coff=16, four_waves=True)
     print('emulation OK')
