@@ -129,3 +129,21 @@ def test_round5_bench_lines(name, pipelined, head):
             assert r[f'also_{tag}_value'] == rec['value'] and r[f'also_{tag}_roofline_frac'] == rec['roofline']['frac']
         assert r['also_headline_one_forward_at_a_time_value'] < r['value'] < r['also_headline_with_head_gemms_on_bf16x6_value']
         assert r['parity']['betas_l2'] < 1e-6 and r['cpu_baseline']['kind'] == 'port'
+
+
+def test_round6_pmc_pass_over_the_benchmarked_plan_feeds_roofline():
+    """the committed PMC pass that `roofline.traffic` / `roofline.mfma_busy` quote was taken over the
+    four-lane plan (not --single-stream) and carries the MFMA busy cycles per forward; the closing bench line holds
+    the derived fractions."""
+    import bench
+    t = bench.pmc_traffic(64, 224, 'f32', 'winograd4')
+    assert t is not None and t['source'].startswith('profiles/r06')
+    assert 'four lanes' in t['pmc_plan'] and t['mfma_busy_cycles_per_forward'] > 1e10
+    # executed MFMA FLOPs of one forward = busy cycles / 32 * 2,048: the counter reproduces the plan's count to 1 %
+    with open(osp.join(ROOT, 'profiles', 'r06r_bench_default_with_also.json')) as f:
+        r = json.load(f)
+    rf = r['roofline']
+    assert abs(t['mfma_busy_cycles_per_forward'] / 32 * 2048 / rf['flop_per_launch_group'] - 1) < 0.01
+    mb = rf['mfma_busy']
+    assert 0.4 < mb['frac_of_simd_cycles_at_2.4GHz'] < mb['frac_of_simd_cycles_at_2.1GHz'] < 0.75
+    assert r['value'] > 5300 and rf['frac'] > 0.54 and r['parity']['betas_l2'] < 1e-4
